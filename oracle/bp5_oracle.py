@@ -1,0 +1,405 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- numpy restatement of the BP5 hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+file.  The product path (deal-and-ceed-on-gpu_amd/) never does.
+
+PARITY UNPINNED: the reference (peterrum/deal-and-ceed-on-gpu) holds no golden vectors,
+known-answer tests or fixtures for this path (its tests/ directory holds one MPI smoke test,
+tests/cuda_aware_mpi.cc) and its arithmetic lives in deal.II 9.2.0-pre (fork
+peterrum/dealii, branch dealii-on-gpu; scripts/daint-gcc/make_dealii.sh:91), which is neither
+vendored in /root/reference nor installed here.  The oracle is therefore pinned by the
+mathematical known-answer tests of SURVEY.md Appendix A.7 (tests/test_oracle_known_answers.py)
+and restates the published algorithm, following these reference call sites:
+
+  * 1-D tables / local numbering ....... bp5/fe_evaluation_gl.h:139-142, bp5/step-64.cu:243-247
+  * merged metric (6 planes, order) .... bp5/step-64.cu:84-114
+  * per-cell operator .................. bp5/step-64.cu:147-194   (cell offset FIXED)
+  * unmerged metric K, JxW ............. bp5/fe_evaluation_gl.h:318-369
+  * vmult + Dirichlet copy ............. bp5/step-64.cu:263-276
+  * RHS b_i = int phi_i ................ bp5/step-64.cu:372-418
+  * plain PCG (parity target) .......... bp5/step-64.cu:428-453 (+ deal.II SolverCG, App. A.5)
+  * fused PCG scalar formulas .......... bp5/solver.h:343-542    (x schedule FIXED)
+  * mesh family ........................ bp5/step-64.cu:629-663
+"""
+from __future__ import annotations
+
+import numpy as np
+from numpy.polynomial import legendre as _L
+
+QUAD_GAUSS = 0  # QGauss<1>(p+1), reference default (bp5/step-64.cu:246)
+QUAD_GLL = 1    # QGaussLobatto<1>(p+1), "COLLOCATION" (bp5/step-64.cu:244)
+
+# plane order of the merged symmetric metric, bp5/step-64.cu:107-113
+PLANE_PAIRS = ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))
+
+
+# ----------------------------------------------------------------------------- 1-D data (A.1)
+def gauss_01(n):
+    x, w = _L.leggauss(n)
+    return (x + 1.0) / 2.0, w / 2.0
+
+
+def gll_01(n):
+    """Gauss-Lobatto-Legendre points/weights on [0,1] (FE_Q(p) support points, n = p+1)."""
+    assert n >= 2
+    c = np.zeros(n)
+    c[-1] = 1.0                        # P_{n-1}
+    if n == 2:
+        x = np.array([-1.0, 1.0])
+    else:
+        xi = _L.legroots(_L.legder(c))
+        for _ in range(3):             # Newton polish of P'_{n-1}
+            xi = xi - _L.legval(xi, _L.legder(c)) / _L.legval(xi, _L.legder(c, 2))
+        x = np.concatenate([[-1.0], np.sort(xi), [1.0]])
+    x = 0.5 * (x - x[::-1])            # enforce exact antisymmetry
+    w = 2.0 / (n * (n - 1) * _L.legval(x, c) ** 2)
+    return (x + 1.0) / 2.0, w / 2.0
+
+
+def lagrange_tables(nodes, points):
+    """N[q][i] = phi_i(x_q), D[q][i] = phi_i'(x_q); phi_i Lagrange on `nodes` (both on [0,1])."""
+    nodes = np.asarray(nodes, dtype=np.float64)
+    points = np.asarray(points, dtype=np.float64)
+    n = len(nodes)
+    N = np.zeros((len(points), n))
+    D = np.zeros((len(points), n))
+    for q, x in enumerate(points):
+        for i in range(n):
+            den = 1.0
+            for m in range(n):
+                if m != i:
+                    den *= nodes[i] - nodes[m]
+            num = 1.0
+            for m in range(n):
+                if m != i:
+                    num *= x - nodes[m]
+            N[q, i] = num / den
+            s = 0.0
+            for l in range(n):
+                if l == i:
+                    continue
+                t = 1.0
+                for m in range(n):
+                    if m != i and m != l:
+                        t *= x - nodes[m]
+                s += t
+            D[q, i] = s / den
+    return N, D
+
+
+def shape_tables(p, quadrature):
+    """(nodes, points, weights, N, D) for FE_Q(p) on GLL nodes with Gauss(p+1) or GLL(p+1)."""
+    n = p + 1
+    nodes, _ = gll_01(n)
+    if quadrature == QUAD_GLL:
+        pts, w = gll_01(n)
+    elif quadrature == QUAD_GAUSS:
+        pts, w = gauss_01(n)
+    else:
+        raise ValueError("quadrature")
+    N, D = lagrange_tables(nodes, pts)
+    if quadrature == QUAD_GLL:
+        N = np.eye(n)                  # collocation: identity interpolation, exactly
+    return nodes, pts, w, N, D
+
+
+# ----------------------------------------------------------------------------- mesh (A.2, bp5/step-64.cu:629-663)
+def kappa_none(X):
+    return np.ones(X.shape[:-1])
+
+
+def kappa_step64(X):
+    """step-64/step-64.cu:117 coefficient 10/(0.05+2|x|^2), used as kappa for 'variable coefficient'."""
+    return 10.0 / (0.05 + 2.0 * np.sum(X * X, axis=-1))
+
+
+def deform_sine(X, L, amp):
+    """Boundary-preserving smooth displacement (the build's definition)."""
+    s = (np.sin(2 * np.pi * X[..., 0] / L[0]) * np.sin(2 * np.pi * X[..., 1] / L[1])
+         * np.sin(2 * np.pi * X[..., 2] / L[2]))
+    out = X.copy()
+    for c, sc in enumerate((1.0, -0.8, 0.6)):
+        out[..., c] += amp * sc * L[c] * s
+    return out
+
+
+class BrickMesh:
+    """n0 x n1 x n2 cubes of side h on [0,n0 h]x[0,n1 h]x[0,n2 h], FE_Q(p), lexicographic numbering.
+
+    local index i + n(j + n k)   (bp5/fe_evaluation_gl.h:139-142)
+    cell  index cx + n0 (cy + n1 cz)
+    global DoF  I + NX (J + NY K), I = p cx + i ...
+    Zero Dirichlet on the whole boundary (bp5/step-64.cu:354-357).
+    """
+
+    def __init__(self, p, cells, h=1.0, deform_amp=0.0):
+        self.p = p
+        self.n = n = p + 1
+        self.cells = tuple(int(c) for c in cells)
+        n0, n1, n2 = self.cells
+        self.h = h
+        self.L = (n0 * h, n1 * h, n2 * h)
+        self.NX, self.NY, self.NZ = p * n0 + 1, p * n1 + 1, p * n2 + 1
+        self.n_dofs = self.NX * self.NY * self.NZ
+        self.n_cells = n0 * n1 * n2
+        nodes, _ = gll_01(n)
+        cx, cy, cz = np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2), indexing="ij")
+        # cell id = cx + n0*(cy + n1*cz): order arrays accordingly
+        cid = (cx + n0 * (cy + n1 * cz)).ravel()
+        order = np.argsort(cid)
+        cx, cy, cz = cx.ravel()[order], cy.ravel()[order], cz.ravel()[order]
+        i = np.arange(n)
+        I = p * cx[:, None, None, None] + i[None, None, None, :]
+        J = p * cy[:, None, None, None] + i[None, None, :, None]
+        K = p * cz[:, None, None, None] + i[None, :, None, None]
+        gid = I + self.NX * (J + self.NY * K)          # [cell][k][j][i]
+        self.l2g = gid.reshape(self.n_cells, n ** 3).astype(np.uint32)
+        # coordinates of global DoFs
+        gx = (np.arange(self.NX) // p + nodes[np.arange(self.NX) % p]) * h
+        gx[-1] = n0 * h
+        gy = (np.arange(self.NY) // p + nodes[np.arange(self.NY) % p]) * h
+        gy[-1] = n1 * h
+        gz = (np.arange(self.NZ) // p + nodes[np.arange(self.NZ) % p]) * h
+        gz[-1] = n2 * h
+        Z, Y, X = np.meshgrid(gz, gy, gx, indexing="ij")
+        coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=-1)
+        if deform_amp != 0.0:
+            coords = deform_sine(coords, self.L, deform_amp)
+        self.coords = coords                            # [n_dofs][3]
+        Ig, Jg, Kg = np.meshgrid(np.arange(self.NX), np.arange(self.NY), np.arange(self.NZ), indexing="ij")
+        bnd = ((Ig == 0) | (Ig == self.NX - 1) | (Jg == 0) | (Jg == self.NY - 1)
+               | (Kg == 0) | (Kg == self.NZ - 1))
+        g = (Ig + self.NX * (Jg + self.NY * Kg))[bnd]
+        self.constrained = np.sort(g.ravel()).astype(np.uint32)
+
+
+# ----------------------------------------------------------------------------- geometry (A.3)
+def _grad_ref(u, N, D):
+    """u: [..., k, j, i] nodal values -> (g0,g1,g2) reference gradients at q-points [..., qk, qj, qi].
+
+    g0 = (N (x) N (x) D) u differentiates along x (fastest index), A.4.
+    """
+    g0 = np.einsum("ck,bj,ai,...kji->...cba", N, N, D, u, optimize=True)
+    g1 = np.einsum("ck,bj,ai,...kji->...cba", N, D, N, u, optimize=True)
+    g2 = np.einsum("ck,bj,ai,...kji->...cba", D, N, N, u, optimize=True)
+    return g0, g1, g2
+
+
+def _interp(u, N):
+    return np.einsum("ck,bj,ai,...kji->...cba", N, N, N, u, optimize=True)
+
+
+def jacobians(mesh, N, D, w):
+    """K = J^{-1} (K[d][e] = d xi_d / d x_e, bp5/fe_evaluation_gl.h:334-343), JxW, q-point coords."""
+    n = mesh.n
+    Xc = mesh.coords[mesh.l2g.astype(np.int64)].reshape(mesh.n_cells, n, n, n, 3)
+    J = np.empty((mesh.n_cells, n, n, n, 3, 3))
+    for e in range(3):
+        g = _grad_ref(Xc[..., e], N, D)
+        for d in range(3):
+            J[..., e, d] = g[d]                        # J[e][d] = d x_e / d xi_d
+    K = np.linalg.inv(J)
+    det = np.linalg.det(J)
+    W = w[:, None, None] * w[None, :, None] * w[None, None, :]
+    JxW = np.abs(det) * W[None]
+    xq = np.stack([_interp(Xc[..., e], N) for e in range(3)], axis=-1)
+    nq = n ** 3
+    return K.reshape(mesh.n_cells, nq, 3, 3), JxW.reshape(mesh.n_cells, nq), xq.reshape(mesh.n_cells, nq, 3)
+
+
+def merged_metric(mesh, N, D, w, kappa=kappa_none):
+    """coef[c][cell][q] = kappa(x_q) * JxW * (K K^T)_c, six planes (bp5/step-64.cu:98-113)."""
+    K, JxW, xq = jacobians(mesh, N, D, w)
+    G = np.einsum("cqdf,cqef->cqde", K, K)
+    s = JxW * kappa(xq)
+    coef = np.stack([s * G[:, :, d, e] for (d, e) in PLANE_PAIRS], axis=0)
+    return np.ascontiguousarray(coef)
+
+
+# ----------------------------------------------------------------------------- operator (A.4)
+def apply_cells(mesh, coef, N, D, src, chunk=4096):
+    """dst = sum_cells P^T B^T S B P src  (no Dirichlet step), bp5/step-64.cu:147-194."""
+    n = mesh.n
+    dst = np.zeros(mesh.n_dofs)
+    for c0 in range(0, mesh.n_cells, chunk):
+        c1 = min(mesh.n_cells, c0 + chunk)
+        idx = mesh.l2g[c0:c1].astype(np.int64)
+        u = src[idx].reshape(c1 - c0, n, n, n)
+        g0, g1, g2 = _grad_ref(u, N, D)
+        S = coef[:, c0:c1].reshape(6, c1 - c0, n, n, n)
+        t0 = S[0] * g0 + S[3] * g1 + S[4] * g2
+        t1 = S[3] * g0 + S[1] * g1 + S[5] * g2
+        t2 = S[4] * g0 + S[5] * g1 + S[2] * g2
+        y = (np.einsum("ck,bj,ai,...cba->...kji", N, N, D, t0, optimize=True)
+             + np.einsum("ck,bj,ai,...cba->...kji", N, D, N, t1, optimize=True)
+             + np.einsum("ck,bj,ai,...cba->...kji", D, N, N, t2, optimize=True))
+        np.add.at(dst, idx.ravel(), y.reshape(-1))
+    return dst
+
+
+def apply_cells_unmerged(mesh, K, JxW, N, D, src, kappa_q=None):
+    """Same operator through submit_gradient(get_gradient()) (bp5/step-64.cu:190,
+    bp5/fe_evaluation_gl.h:318-369): t = JxW * K (K^T ghat)."""
+    n = mesh.n
+    dst = np.zeros(mesh.n_dofs)
+    idx = mesh.l2g.astype(np.int64)
+    u = src[idx].reshape(mesh.n_cells, n, n, n)
+    g = np.stack([x.reshape(mesh.n_cells, -1) for x in _grad_ref(u, N, D)], axis=-1)  # [c][q][d]
+    phys = np.einsum("cqde,cqd->cqe", K, g)           # grad_x = K^T ghat
+    s = JxW if kappa_q is None else JxW * kappa_q
+    t = np.einsum("cqde,cqe->cqd", K, phys) * s[..., None]
+    t = t.reshape(mesh.n_cells, n, n, n, 3)
+    y = (np.einsum("ck,bj,ai,...cba->...kji", N, N, D, t[..., 0], optimize=True)
+         + np.einsum("ck,bj,ai,...cba->...kji", N, D, N, t[..., 1], optimize=True)
+         + np.einsum("ck,bj,ai,...cba->...kji", D, N, N, t[..., 2], optimize=True))
+    np.add.at(dst, idx.ravel(), y.reshape(-1))
+    return dst
+
+
+def vmult(mesh, coef, N, D, src):
+    """PoissonOperator::vmult (bp5/step-64.cu:263-276): cell loop on unmodified src, then
+    dst[c] = src[c] on Dirichlet DoFs."""
+    dst = apply_cells(mesh, coef, N, D, src)
+    c = mesh.constrained.astype(np.int64)
+    dst[c] = src[c]
+    return dst
+
+
+def element_matrix(coef_cell, N, D):
+    """Dense B^T S B for one cell (A.7-6). coef_cell: [6][nq^3]."""
+    n = N.shape[1]
+    nq = N.shape[0]
+    B = np.zeros((3, nq ** 3, n ** 3))
+    B[0] = np.kron(N, np.kron(N, D))
+    B[1] = np.kron(N, np.kron(D, N))
+    B[2] = np.kron(D, np.kron(N, N))
+    A = np.zeros((n ** 3, n ** 3))
+    for c, (d, e) in enumerate(PLANE_PAIRS):
+        A += B[d].T @ (coef_cell[c][:, None] * B[e])
+        if d != e:
+            A += B[e].T @ (coef_cell[c][:, None] * B[d])
+    return A
+
+
+# ----------------------------------------------------------------------------- RHS (A.6)
+def assemble_rhs(mesh, w_unused=None):
+    """b_i = sum_cells sum_q phi_i(x_q) JxW(q) with Gauss(p+1) (bp5/step-64.cu:380,401-405),
+    constrained rows 0 (bp5/step-64.cu:409-411)."""
+    _, _, w, N, D = shape_tables(mesh.p, QUAD_GAUSS)
+    _, JxW, _ = jacobians(mesh, N, D, w)
+    n = mesh.n
+    y = np.einsum("ck,bj,ai,...cba->...kji", N, N, N, JxW.reshape(mesh.n_cells, n, n, n), optimize=True)
+    b = np.zeros(mesh.n_dofs)
+    np.add.at(b, mesh.l2g.astype(np.int64).ravel(), y.reshape(-1))
+    b[mesh.constrained.astype(np.int64)] = 0.0
+    return b
+
+
+# ----------------------------------------------------------------------------- CG (A.5)
+def cg_plain(A, b, max_iter, tol=0.0, diag=None, x0=None, dtype=np.float64, history=None):
+    """deal.II SolverCG recurrence (bp5/step-64.cu:446-453, Appendix A.5), IterationNumberControl:
+    stop at res <= tol or k == max_iter.  Returns (x, iterations, last residual)."""
+    b = b.astype(dtype)
+    x = np.zeros_like(b) if x0 is None else x0.astype(dtype).copy()
+    one = np.ones_like(b) if diag is None else diag.astype(dtype)
+    g = -b.copy() if x0 is None else (A(x) - b)
+    res = np.sqrt(g @ g)
+    if res <= tol:
+        return x, 0, res
+    h = one * g
+    d = -h
+    gh = g @ h
+    k = 0
+    while True:
+        k += 1
+        h = A(d).astype(dtype)
+        alpha = gh / (d @ h)
+        x = x + alpha * d
+        g = g + alpha * h
+        res = np.sqrt(g @ g)
+        if history is not None:
+            history.append(float(res))
+        if res <= tol or k == max_iter:
+            return x, k, res
+        h = one * g
+        gh_old = gh
+        gh = g @ h
+        beta = gh / gh_old
+        d = beta * d - h
+
+
+def cg_merged(A, b, max_iter, tol=0.0, diag=None, history=None):
+    """SolverCGFullMerge (bp5/solver.h:343-542) with the x-update schedule FIXED:
+    it==1 update_a0, even it update_a<false>, odd it>=3 update_a1; epilogue as solver.h:510-526."""
+    x = np.zeros_like(b)
+    D_ = np.ones_like(b) if diag is None else diag
+    r = -b.copy()
+    res = np.sqrt(r @ r)
+    if res <= tol:
+        return x, 0, res
+    p = np.zeros_like(b)
+    v = np.zeros_like(b)
+    alpha = beta = alpha_old = beta_old = 0.0
+    it = 0
+    while True:
+        it += 1
+        if it == 1:                                     # update_a0, solver.h:48-72
+            p = -D_ * r
+        elif it % 2 == 0:                               # update_a<false>, solver.h:74-104
+            r = r + alpha * v
+            p = beta * p - D_ * r
+        else:                                           # update_a1, solver.h:106-140
+            r_old = r
+            x = x + (alpha + alpha_old / beta_old) * p + (alpha_old / beta_old) * (D_ * r_old)
+            r = r + alpha * v
+            p = beta * p - D_ * r
+        v = A(p)
+        # update_b: 7 dots, solver.h:142-311
+        R = np.array([p @ v, v @ v, r @ v, r @ r, r @ (D_ * v), v @ (D_ * v), r @ (D_ * r)])
+        alpha_old, beta_old = alpha, beta
+        alpha = R[6] / R[0]                              # solver.h:502
+        res = np.sqrt(max(R[3] + 2 * alpha * R[2] + alpha * alpha * R[1], 0.0))  # solver.h:504-505
+        if history is not None:
+            history.append(float(res))
+        if res <= tol or it == max_iter:
+            if it % 2 == 1:
+                x = x + alpha * p                        # solver.h:511
+            else:                                        # update_c, solver.h:315-336,513-525
+                x = x + (alpha + alpha_old / beta_old) * p + (alpha_old / beta_old) * (D_ * r)
+            return x, it, res
+        beta = alpha * (R[4] + alpha * R[5]) / R[6]      # solver.h:533
+
+
+# ----------------------------------------------------------------------------- post-processing
+def l2_norm_solution(mesh, u):
+    """||u_h||_L2 by Gauss(p+1) quadrature (bp5/step-64.cu:602-616)."""
+    _, _, w, N, D = shape_tables(mesh.p, QUAD_GAUSS)
+    _, JxW, _ = jacobians(mesh, N, D, w)
+    n = mesh.n
+    uq = _interp(u[mesh.l2g.astype(np.int64)].reshape(mesh.n_cells, n, n, n), N).reshape(mesh.n_cells, -1)
+    return float(np.sqrt(np.sum(uq * uq * JxW)))
+
+
+def deterministic_src(n_dofs, constrained=None, seed=20190930):
+    """deterministic pseudo-random f64 in [-1,1], zero on Dirichlet DoFs."""
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(-1.0, 1.0, size=n_dofs)
+    if constrained is not None:
+        s[constrained.astype(np.int64)] = 0.0
+    return s
+
+
+class Problem:
+    """Convenience bundle: mesh + tables + metric + RHS, mirrors PoissonProblem::setup_system."""
+
+    def __init__(self, p, cells, quadrature=QUAD_GAUSS, h=1.0, deform_amp=0.0, kappa=kappa_none):
+        self.mesh = BrickMesh(p, cells, h=h, deform_amp=deform_amp)
+        self.nodes, self.pts, self.w, self.N, self.D = shape_tables(p, quadrature)
+        self.coef = merged_metric(self.mesh, self.N, self.D, self.w, kappa)
+        self.quadrature = quadrature
+
+    def vmult(self, src):
+        return vmult(self.mesh, self.coef, self.N, self.D, src)
+
+    def rhs(self):
+        return assemble_rhs(self.mesh)

@@ -1,0 +1,180 @@
+"""Known-answer tests that pin the oracle.  The reference has no
+golden vectors for this path, so these mathematical identities are the pins."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import bp5_oracle as O
+
+
+@pytest.mark.parametrize("p", range(1, 9))
+@pytest.mark.parametrize("quad", [O.QUAD_GAUSS, O.QUAD_GLL])
+def test_tables(p, quad):                                            # A.7-1
+    nodes, pts, w, N, D = O.shape_tables(p, quad)
+    assert np.allclose(N.sum(1), 1.0, atol=1e-13)
+    assert np.allclose(D.sum(1), 0.0, atol=1e-11)
+    assert abs(w.sum() - 1.0) < 1e-14
+    for m in range(p + 1):
+        assert np.allclose(N @ nodes ** m, pts ** m, atol=1e-13)
+        ref = m * pts ** (m - 1) if m > 0 else 0 * pts
+        assert np.allclose(D @ nodes ** m, ref, atol=1e-11)
+    if quad == O.QUAD_GLL:
+        assert np.array_equal(N, np.eye(p + 1))
+    # symmetry of the tables under x -> 1-x
+    assert np.allclose(N, N[::-1, ::-1], atol=1e-14)
+    assert np.allclose(D, -D[::-1, ::-1], atol=1e-12)
+    # quadrature exactness: Gauss 2n-1, GLL 2n-3
+    deg = 2 * (p + 1) - (1 if quad == O.QUAD_GAUSS else 3)
+    assert abs(w @ pts ** deg - 1.0 / (deg + 1)) < 1e-14
+
+
+@pytest.mark.parametrize("p,quad,amp", [(1, 0, 0.0), (2, 0, 0.0), (3, 1, 0.0), (4, 0, 0.04), (2, 1, 0.05)])
+def test_nullspace_symmetry_psd(p, quad, amp):                       # A.7-2
+    pr = O.Problem(p, (3, 2, 2), quad, deform_amp=amp)
+    m = pr.mesh
+    one = np.ones(m.n_dofs)
+    a1 = O.apply_cells(m, pr.coef, pr.N, pr.D, one)
+    assert np.abs(a1).max() < 1e-12
+    rng = np.random.default_rng(1)
+    u, v = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    Au, Av = (O.apply_cells(m, pr.coef, pr.N, pr.D, z) for z in (u, v))
+    assert abs(v @ Au - u @ Av) < 1e-11 * abs(v @ Au)
+    assert u @ Au > 0
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_energy_identity_affine(p):                                  # A.7-3
+    pr = O.Problem(p, (2, 3, 2), O.QUAD_GAUSS, h=0.5)
+    m = pr.mesh
+    L = m.L
+    X = m.coords
+    u = X[:, 0]
+    e = u @ O.apply_cells(m, pr.coef, pr.N, pr.D, u)
+    assert abs(e - L[0] * L[1] * L[2]) < 1e-12
+    u = X[:, 0] * X[:, 1]
+    e = u @ O.apply_cells(m, pr.coef, pr.N, pr.D, u)
+    # int (y^2 + x^2) = Lz*(Lx*Ly^3/3 + Ly*Lx^3/3)
+    ref = L[2] * (L[0] * L[1] ** 3 / 3 + L[1] * L[0] ** 3 / 3)
+    assert abs(e - ref) < 1e-12 * ref
+
+
+@pytest.mark.parametrize("p,quad", [(2, 0), (3, 0), (4, 1)])
+def test_deformed_linear_field(p, quad):                             # A.7-4
+    pr = O.Problem(p, (2, 2, 3), quad, deform_amp=0.05)
+    m = pr.mesh
+    a = np.array([0.3, -1.1, 0.7])
+    u = m.coords @ a
+    _, JxW, _ = O.jacobians(m, pr.N, pr.D, pr.w)
+    e = u @ O.apply_cells(m, pr.coef, pr.N, pr.D, u)
+    assert abs(e - (a @ a) * JxW.sum()) < 1e-12 * e
+
+
+def test_merged_vs_unmerged():                                       # A.7-5
+    pr = O.Problem(3, (2, 2, 2), O.QUAD_GAUSS, deform_amp=0.05)
+    m = pr.mesh
+    K, JxW, _ = O.jacobians(m, pr.N, pr.D, pr.w)
+    s = O.deterministic_src(m.n_dofs)
+    a = O.apply_cells(m, pr.coef, pr.N, pr.D, s)
+    b = O.apply_cells_unmerged(m, K, JxW, pr.N, pr.D, s)
+    assert np.linalg.norm(a - b) < 1e-14 * np.linalg.norm(a)
+
+
+@pytest.mark.parametrize("p,quad", [(1, 0), (2, 0), (3, 0), (3, 1)])
+def test_dense_element_matrix(p, quad):                              # A.7-6
+    pr = O.Problem(p, (2, 1, 2), quad, deform_amp=0.03)
+    m = pr.mesh
+    s = O.deterministic_src(m.n_dofs)
+    ref = np.zeros(m.n_dofs)
+    for c in range(m.n_cells):
+        Ae = O.element_matrix(pr.coef[:, c], pr.N, pr.D)
+        idx = m.l2g[c].astype(np.int64)
+        np.add.at(ref, idx, Ae @ s[idx])
+    got = O.apply_cells(m, pr.coef, pr.N, pr.D, s)
+    assert np.linalg.norm(got - ref) < 1e-13 * np.linalg.norm(ref)
+
+
+def _assemble_sparse(pr):
+    m = pr.mesh
+    rows, cols, vals = [], [], []
+    for c in range(m.n_cells):
+        Ae = O.element_matrix(pr.coef[:, c], pr.N, pr.D)
+        idx = m.l2g[c].astype(np.int64)
+        rows.append(np.repeat(idx, len(idx)))
+        cols.append(np.tile(idx, len(idx)))
+        vals.append(Ae.ravel())
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(m.n_dofs, m.n_dofs))
+    Pm = np.ones(m.n_dofs)
+    Pm[m.constrained.astype(np.int64)] = 0
+    Pd = sp.diags(Pm)
+    return (Pd @ A @ Pd + sp.diags(1 - Pm)).tocsr()
+
+
+def test_cg_config1_vs_assembled():                                  # A.7-7 (BASELINE config 1)
+    pr = O.Problem(2, (8, 8, 8), O.QUAD_GAUSS)
+    m = pr.mesh
+    assert m.n_dofs == 4913
+    b = pr.rhs()
+    Aeff = _assemble_sparse(pr)
+    x_mf, k, _ = O.cg_plain(pr.vmult, b, 10)
+    x_as, _, _ = O.cg_plain(lambda v: Aeff @ v, b, 10)
+    assert k == 10
+    assert np.linalg.norm(x_mf - x_as) < 1e-13 * np.linalg.norm(x_as)
+    x_ld, _, _ = O.cg_plain(lambda v: (Aeff @ v.astype(np.float64)).astype(np.longdouble), b, 10,
+                            dtype=np.longdouble)
+    assert np.linalg.norm(x_mf - x_ld.astype(np.float64)) < 1e-12 * np.linalg.norm(x_as)
+    x_mg, k2, _ = O.cg_merged(pr.vmult, b, 10)
+    assert k2 == 10
+    assert np.linalg.norm(x_mg - x_mf) < 1e-13 * np.linalg.norm(x_mf)
+    x_mg, _, _ = O.cg_merged(pr.vmult, b, 9)                          # odd epilogue
+    x_p9, _, _ = O.cg_plain(pr.vmult, b, 9)
+    assert np.linalg.norm(x_mg - x_p9) < 1e-13 * np.linalg.norm(x_p9)
+    # converged CG vs direct solve
+    x_cv, k3, _ = O.cg_plain(pr.vmult, b, 2000, tol=1e-13 * np.linalg.norm(b))
+    x_dir = spla.spsolve(Aeff.tocsc(), b)
+    assert np.linalg.norm(x_cv - x_dir) < 1e-10 * np.linalg.norm(x_dir)
+
+
+def test_rhs_sum_and_volume():                                       # A.7-9
+    m = O.BrickMesh(3, (2, 3, 2), h=0.5)
+    _, _, w, N, D = O.shape_tables(3, O.QUAD_GAUSS)
+    _, JxW, _ = O.jacobians(m, N, D, w)
+    assert abs(JxW.sum() - 1.0 * 1.5 * 1.0) < 1e-13
+    b = O.assemble_rhs(m)
+    assert np.all(b[m.constrained.astype(np.int64)] == 0)
+    # unconstrained sum = |Omega|
+    n = m.n
+    y = np.einsum("ck,bj,ai,...cba->...kji", N, N, N, JxW.reshape(m.n_cells, n, n, n))
+    assert abs(y.sum() - 1.5) < 1e-13
+
+
+def test_manufactured_convergence():                                 # A.7-8
+    errs = []
+    p = 2
+    for nc in (2, 4, 8):
+        pr = O.Problem(p, (nc, nc, nc), O.QUAD_GAUSS, h=1.0 / nc)
+        m = pr.mesh
+        # rhs: f = 3 pi^2 prod sin(pi x); b_i = int f phi_i  with Gauss(p+1)
+        K, JxW, xq = O.jacobians(m, pr.N, pr.D, pr.w)
+        f = 3 * np.pi ** 2 * np.prod(np.sin(np.pi * xq), axis=-1) * JxW
+        n = m.n
+        y = np.einsum("ck,bj,ai,...cba->...kji", pr.N, pr.N, pr.N, f.reshape(m.n_cells, n, n, n))
+        b = np.zeros(m.n_dofs)
+        np.add.at(b, m.l2g.astype(np.int64).ravel(), y.ravel())
+        b[m.constrained.astype(np.int64)] = 0
+        x, _, _ = O.cg_plain(pr.vmult, b, 3000, tol=1e-12 * np.linalg.norm(b))
+        uex = np.prod(np.sin(np.pi * m.coords), axis=-1)
+        errs.append(O.l2_norm_solution(m, x - uex))
+    rate = np.log2(errs[-2] / errs[-1])
+    assert rate > p + 0.7, (errs, rate)
+
+
+def test_merged_cg_reference_bug_documented():
+    """running update_a1 on EVERY iteration >= 3 (as bp5/solver.h:425-448 does)
+    gives a wrong x; our fixed schedule reproduces plain CG.  Guard that we did not inherit it."""
+    pr = O.Problem(2, (3, 3, 3), O.QUAD_GAUSS)
+    b = pr.rhs()
+    x6, _, _ = O.cg_merged(pr.vmult, b, 6)
+    xp, _, _ = O.cg_plain(pr.vmult, b, 6)
+    assert np.linalg.norm(x6 - xp) < 1e-13 * np.linalg.norm(xp)
