@@ -1,0 +1,794 @@
+// C-ABI implementation: MatrixFree handle, operator launches, BLAS-1, CG drivers, RCCL halo.
+// Every entry point cites the reference interface it replaces in include/bp5.h.
+#include "bp5_internal.hpp"
+#include "bp5_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace bp5;
+
+#define HIP_TRY(expr)                                                                                              \
+  do {                                                                                                             \
+    hipError_t e_ = (expr);                                                                                        \
+    if (e_ != hipSuccess)                                                                                          \
+      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? BP5_ERR_NO_DEVICE : BP5_ERR_HIP,         \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                              \
+  } while (0)
+#define NCCL_TRY(expr)                                                                                             \
+  do {                                                                                                             \
+    ncclResult_t r_ = (expr);                                                                                      \
+    if (r_ != ncclSuccess) return fail(BP5_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));         \
+  } while (0)
+#define BP5_TRY(expr)                                                                                              \
+  do {                                                                                                             \
+    int s_ = (expr);                                                                                               \
+    if (s_ != BP5_OK) return s_;                                                                                   \
+  } while (0)
+#define KERNEL_CHECK() HIP_TRY(hipGetLastError())
+
+struct bp5_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 1;
+};
+struct bp5_event {
+  hipEvent_t ev = nullptr;
+};
+
+struct bp5_mf {
+  int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
+  uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
+  int apply_variant = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Tables tab, tab_gauss;
+  // device arrays
+  uint32_t *d_l2g = nullptr, *d_constrained = nullptr, *d_send_idx = nullptr;
+  double *d_coords = nullptr, *d_tab = nullptr, *d_tab_gauss = nullptr;
+  // Data mirror (lazy)
+  uint32_t *d_l2g_padded = nullptr, *d_constraint_mask = nullptr;
+  double *d_inv_jac = nullptr, *d_JxW = nullptr, *d_qpoints = nullptr;
+  uint32_t pad = 0;
+  // halo plan
+  std::vector<int> neighbors;
+  std::vector<uint32_t> send_off, recv_off;
+  double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+  bp5_comm *comm = nullptr;
+  // solver workspace
+  double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
+  int *d_st = nullptr;
+  double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr;
+  double *h_sc = nullptr; // pinned
+  int *h_st = nullptr;    // pinned
+  std::vector<hipEvent_t> ev_pool;
+  size_t n_local() const { return (size_t)n_owned + n_ghost; }
+};
+
+// ------------------------------------------------------------------------------------ device / vectors
+extern "C" int bp5_device_count(int *count)
+{
+  if (!count) return fail(BP5_ERR_INVALID, "null argument");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *count = 0; return fail(BP5_ERR_NO_DEVICE, hipGetErrorString(e)); }
+  *count = c;
+  return BP5_OK;
+}
+extern "C" int bp5_vec_alloc(size_t n, double **out)
+{
+  if (!out) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipMalloc((void **)out, std::max<size_t>(n, 1) * sizeof(double)));
+  HIP_TRY(hipMemset(*out, 0, std::max<size_t>(n, 1) * sizeof(double)));
+  return BP5_OK;
+}
+extern "C" int bp5_vec_free(double *v) { HIP_TRY(hipFree(v)); return BP5_OK; }
+extern "C" int bp5_copy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return BP5_OK; }
+extern "C" int bp5_copy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return BP5_OK; }
+
+// ------------------------------------------------------------------------------------ create / destroy
+template <typename T>
+static int upload(T **dptr, const T *host, size_t count)
+{
+  HIP_TRY(hipMalloc((void **)dptr, std::max<size_t>(count, 1) * sizeof(T)));
+  if (count) HIP_TRY(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+  return BP5_OK;
+}
+static void pack_tab(const Tables &t, std::vector<double> &v)
+{
+  const int n = t.n;
+  v.assign(2 * n * n + n, 0.0);
+  memcpy(v.data(), t.N, n * n * sizeof(double));
+  memcpy(v.data() + n * n, t.D, n * n * sizeof(double));
+  memcpy(v.data() + 2 * n * n, t.w, n * sizeof(double));
+}
+
+extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
+{
+  if (!d || !out) return fail(BP5_ERR_INVALID, "null argument");
+  if (d->dim != 3) return fail(BP5_ERR_UNSUPPORTED, "only dim == 3");
+  if (!d->local_to_global_host || !d->node_coords_host) return fail(BP5_ERR_INVALID, "mesh arrays missing");
+  if (d->n_interior_cells > d->n_cells) return fail(BP5_ERR_INVALID, "n_interior_cells > n_cells");
+  Tables tab, tabg;
+  BP5_TRY(shape_tables(d->degree, d->quadrature, tab));
+  BP5_TRY(shape_tables(d->degree, BP5_QUAD_GAUSS, tabg));
+  int ndev = 0;
+  BP5_TRY(bp5_device_count(&ndev));
+  if (ndev <= 0) return fail(BP5_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+  if (d->device < 0 || d->device >= ndev) return fail(BP5_ERR_INVALID, "bad device ordinal");
+  HIP_TRY(hipSetDevice(d->device));
+  bp5_mf *mf = new bp5_mf;
+  mf->degree = d->degree; mf->quadrature = d->quadrature; mf->coefficient = d->coefficient;
+  mf->n = d->degree + 1; mf->n3 = mf->n * mf->n * mf->n; mf->device = d->device;
+  mf->n_cells = d->n_cells; mf->n_interior = d->n_interior_cells; mf->n_owned = d->n_owned; mf->n_ghost = d->n_ghost;
+  mf->n_constrained = d->n_constrained;
+  mf->tab = tab; mf->tab_gauss = tabg;
+  // validate indices on the host: a bad index would fault on the GPU
+  const size_t nl = (size_t)d->n_cells * mf->n3, nloc = mf->n_local();
+  for (size_t s = 0; s < nl; ++s)
+    if (d->local_to_global_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "local_to_global entry out of range"); }
+  for (uint32_t s = 0; s < d->n_constrained; ++s)
+    if (d->constrained_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "constrained index out of range"); }
+  if (d->stream) mf->stream = (hipStream_t)d->stream;
+  else { HIP_TRY(hipStreamCreateWithFlags(&mf->stream, hipStreamNonBlocking)); mf->own_stream = true; }
+  BP5_TRY(upload(&mf->d_l2g, d->local_to_global_host, nl));
+  BP5_TRY(upload(&mf->d_coords, d->node_coords_host, nloc * 3));
+  BP5_TRY(upload(&mf->d_constrained, d->constrained_host, d->n_constrained));
+  std::vector<double> tv;
+  pack_tab(tab, tv);  BP5_TRY(upload(&mf->d_tab, tv.data(), tv.size()));
+  pack_tab(tabg, tv); BP5_TRY(upload(&mf->d_tab_gauss, tv.data(), tv.size()));
+  // halo plan
+  if (d->n_neighbors > 0) {
+    if (!d->neighbor_rank_host || !d->send_offsets_host || !d->recv_offsets_host) { delete mf; return fail(BP5_ERR_INVALID, "halo plan arrays missing"); }
+    mf->neighbors.assign(d->neighbor_rank_host, d->neighbor_rank_host + d->n_neighbors);
+    mf->send_off.assign(d->send_offsets_host, d->send_offsets_host + d->n_neighbors + 1);
+    mf->recv_off.assign(d->recv_offsets_host, d->recv_offsets_host + d->n_neighbors + 1);
+    const uint32_t ns = mf->send_off.back();
+    if (mf->recv_off.back() != d->n_ghost) { delete mf; return fail(BP5_ERR_INVALID, "recv ranges must cover the ghost range"); }
+    for (uint32_t s = 0; s < ns; ++s)
+      if (d->send_indices_host[s] >= d->n_owned) { delete mf; return fail(BP5_ERR_INVALID, "send index out of owned range"); }
+    BP5_TRY(upload(&mf->d_send_idx, d->send_indices_host, ns));
+    HIP_TRY(hipMalloc((void **)&mf->d_sendbuf, std::max<size_t>(ns, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&mf->d_recvbuf, std::max<size_t>(ns, 1) * sizeof(double)));
+  } else if (d->n_ghost) { delete mf; return fail(BP5_ERR_INVALID, "ghosts without a halo plan"); }
+  // solver workspace
+  HIP_TRY(hipMalloc((void **)&mf->d_partials, 8 * MAXBLK * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&mf->d_sc, SC_COUNT * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&mf->d_scalar, 8 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&mf->d_st, ST_COUNT * sizeof(int)));
+  HIP_TRY(hipMemset(mf->d_sc, 0, SC_COUNT * sizeof(double)));
+  HIP_TRY(hipMemset(mf->d_st, 0, ST_COUNT * sizeof(int)));
+  HIP_TRY(hipHostMalloc((void **)&mf->h_sc, SC_COUNT * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void **)&mf->h_st, ST_COUNT * sizeof(int)));
+  *out = mf;
+  return BP5_OK;
+}
+
+extern "C" int bp5_mf_destroy(bp5_mf *mf)
+{
+  if (!mf) return BP5_OK;
+  hipSetDevice(mf->device);
+  hipStreamSynchronize(mf->stream);
+  void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
+                  mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_g, mf->ws_d, mf->ws_h};
+  for (void *p : ptrs) if (p) hipFree(p);
+  if (mf->h_sc) hipHostFree(mf->h_sc);
+  if (mf->h_st) hipHostFree(mf->h_st);
+  for (hipEvent_t e : mf->ev_pool) hipEventDestroy(e);
+  if (mf->own_stream) hipStreamDestroy(mf->stream);
+  delete mf;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_set_stream(bp5_mf *mf, void *s)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  if (mf->own_stream) { hipStreamSynchronize(mf->stream); hipStreamDestroy(mf->stream); mf->own_stream = false; }
+  mf->stream = (hipStream_t)s;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_sync(bp5_mf *mf)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  HIP_TRY(hipStreamSynchronize(mf->stream));
+  return BP5_OK;
+}
+extern "C" int bp5_mf_coef_size(const bp5_mf *mf, size_t *n)
+{
+  if (!mf || !n) return fail(BP5_ERR_INVALID, "null argument");
+  *n = (size_t)6 * mf->n_cells * mf->n3;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  mf->apply_variant = v;
+  return BP5_OK;
+}
+
+// ------------------------------------------------------------------------------------ geometry
+template <int n>
+static int launch_geometry(bp5_mf *mf, GeomOut o)
+{
+  const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 65535u * 16);
+  hipLaunchKernelGGL(geometry_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab, mf->coefficient,
+                     mf->n_cells, o);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+#define DISPATCH_N(fn, ...)                                                                                        \
+  switch (mf->n) {                                                                                                 \
+    case 2: return fn<2>(__VA_ARGS__);                                                                             \
+    case 3: return fn<3>(__VA_ARGS__);                                                                             \
+    case 4: return fn<4>(__VA_ARGS__);                                                                             \
+    case 5: return fn<5>(__VA_ARGS__);                                                                             \
+    case 6: return fn<6>(__VA_ARGS__);                                                                             \
+    case 7: return fn<7>(__VA_ARGS__);                                                                             \
+    case 8: return fn<8>(__VA_ARGS__);                                                                             \
+    case 9: return fn<9>(__VA_ARGS__);                                                                             \
+  }                                                                                                                \
+  return fail(BP5_ERR_INVALID, "unsupported degree")
+
+extern "C" int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef)
+{
+  if (!mf || !coef) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  GeomOut o{};
+  o.coef = coef;
+  o.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  DISPATCH_N(launch_geometry, mf, o);
+}
+
+template <int n>
+static int launch_permute(bp5_mf *mf, const double *in, double *out)
+{
+  const uint64_t total = (uint64_t)6 * mf->n_cells * mf->n3;
+  hipLaunchKernelGGL(metric_permute_kernel<n>, dim3(2048), dim3(256), 0, mf->stream, in, out, total);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_mf_metric_to_reference_layout(bp5_mf *mf, const double *coef, double *coef_ref)
+{
+  if (!mf || !coef || !coef_ref) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  DISPATCH_N(launch_permute, mf, coef, coef_ref);
+}
+
+static uint32_t padding_length(int n)
+{ // deal.II: 2^ceil(dim*log2(n)) [upstream], SURVEY 8(a3)
+  uint32_t p = 1;
+  while (p < (uint32_t)(n * n * n)) p <<= 1;
+  return p;
+}
+static int geometry_data(bp5_mf *mf, GeomOut o) { DISPATCH_N(launch_geometry, mf, o); }
+
+extern "C" int bp5_mf_get_data(bp5_mf *mf, int color, bp5_mf_data *out)
+{
+  if (!mf || !out) return fail(BP5_ERR_INVALID, "null argument");
+  if (color != 0) return fail(BP5_ERR_INVALID, "this build keeps all cells in one colour");
+  HIP_TRY(hipSetDevice(mf->device));
+  if (!mf->d_inv_jac) {
+    mf->pad = padding_length(mf->n);
+    const size_t gp = (size_t)mf->n_cells * mf->pad;
+    HIP_TRY(hipMalloc((void **)&mf->d_inv_jac, std::max<size_t>(9 * gp, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&mf->d_JxW, std::max<size_t>(gp, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&mf->d_qpoints, std::max<size_t>(3 * gp, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&mf->d_l2g_padded, std::max<size_t>(gp, 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&mf->d_constraint_mask, std::max<size_t>(mf->n_cells, 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(mf->d_inv_jac, 0, 9 * gp * sizeof(double), mf->stream));
+    HIP_TRY(hipMemsetAsync(mf->d_JxW, 0, gp * sizeof(double), mf->stream));
+    HIP_TRY(hipMemsetAsync(mf->d_qpoints, 0, 3 * gp * sizeof(double), mf->stream));
+    HIP_TRY(hipMemsetAsync(mf->d_l2g_padded, 0, gp * sizeof(uint32_t), mf->stream));
+    HIP_TRY(hipMemsetAsync(mf->d_constraint_mask, 0, mf->n_cells * sizeof(uint32_t), mf->stream));
+    if (mf->n_cells)
+      HIP_TRY(hipMemcpy2DAsync(mf->d_l2g_padded, mf->pad * sizeof(uint32_t), mf->d_l2g, mf->n3 * sizeof(uint32_t),
+                               mf->n3 * sizeof(uint32_t), mf->n_cells, hipMemcpyDeviceToDevice, mf->stream));
+    GeomOut o{};
+    o.inv_jac = mf->d_inv_jac; o.JxW = mf->d_JxW; o.q_points = mf->d_qpoints; o.pad = mf->pad; o.geo_plane = gp;
+    BP5_TRY(geometry_data(mf, o));
+    HIP_TRY(hipStreamSynchronize(mf->stream));
+  }
+  out->local_to_global = mf->d_l2g_padded; out->inv_jacobian = mf->d_inv_jac; out->JxW = mf->d_JxW; out->q_points = mf->d_qpoints;
+  out->constraint_mask = mf->d_constraint_mask; out->n_cells = mf->n_cells; out->padding_length = mf->pad; out->row_start = 0;
+  out->use_coloring = 0;
+  return BP5_OK;
+}
+
+// ------------------------------------------------------------------------------------ operator
+template <int P, bool COLL, int TW, int LPC, int TPB, bool PF>
+static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 64 * TW / LPC;
+  using L = LdsLayout<n, LPC>;
+  ApplyArgs a;
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = c0; a.cell_end = c1;
+  a.n_teams = (c1 - c0 + CPT - 1) / CPT;
+  const uint32_t nblk = (a.n_teams + TPB - 1) / TPB;
+  a.teams_per_xcd = (nblk + 7) / 8;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const size_t lds = (size_t)TPB * CPT * L::CS * sizeof(double);
+  hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
+                     sh);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+
+// variant table: (degree, variant) -> (TW, LPC, TPB, PF); variant 0 = default for the degree
+#define APPLY_CASE(P, V, TW, LPC, TPB, PF)                                                                         \
+  case (P)*100 + (V):                                                                                              \
+    return coll ? launch_apply_t<P, true, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)                            \
+                : launch_apply_t<P, false, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)
+
+static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
+{
+  if (c1 <= c0) return BP5_OK;
+  const bool coll = mf->quadrature == BP5_QUAD_GLL;
+  switch (mf->degree * 100 + mf->apply_variant) {
+    APPLY_CASE(1, 0, 1, 4, 4, true);
+    APPLY_CASE(2, 0, 1, 9, 4, true);
+    APPLY_CASE(3, 0, 1, 16, 4, true);
+    APPLY_CASE(4, 0, 1, 25, 4, true);
+    APPLY_CASE(4, 1, 1, 32, 4, true);
+    APPLY_CASE(4, 2, 2, 25, 1, true);
+    APPLY_CASE(4, 3, 4, 25, 1, true);
+    APPLY_CASE(4, 4, 1, 25, 1, true);
+    APPLY_CASE(4, 5, 1, 25, 4, false);
+    APPLY_CASE(5, 0, 4, 36, 1, true);
+    APPLY_CASE(5, 1, 1, 36, 4, true);
+    APPLY_CASE(6, 0, 4, 49, 1, false);
+    APPLY_CASE(6, 1, 1, 49, 4, false);
+    APPLY_CASE(7, 0, 1, 64, 4, false);
+    APPLY_CASE(8, 0, 4, 81, 1, false);
+    APPLY_CASE(8, 1, 2, 81, 1, false);
+  }
+  return fail(BP5_ERR_INVALID, "unknown (degree, apply variant)");
+}
+
+extern "C" int bp5_apply_cells(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
+{
+  if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (c1 > mf->n_cells || c0 > c1) return fail(BP5_ERR_INVALID, "cell range out of bounds");
+  if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
+  HIP_TRY(hipSetDevice(mf->device));
+  return launch_apply(mf, coef, src, dst, c0, c1);
+}
+extern "C" int bp5_copy_constrained(bp5_mf *mf, const double *src, double *dst)
+{
+  if (!mf || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf->n_constrained) return BP5_OK;
+  hipLaunchKernelGGL(copy_constrained_kernel, dim3((mf->n_constrained + 255) / 256), dim3(256), 0, mf->stream, mf->d_constrained,
+                     mf->n_constrained, src, dst);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_set_constrained(bp5_mf *mf, double value, double *dst)
+{
+  if (!mf || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf->n_constrained) return BP5_OK;
+  hipLaunchKernelGGL(set_constrained_kernel, dim3((mf->n_constrained + 255) / 256), dim3(256), 0, mf->stream, mf->d_constrained,
+                     mf->n_constrained, value, dst);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, int zero_dst)
+{
+  if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
+  HIP_TRY(hipSetDevice(mf->device));
+  if (zero_dst) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells));
+  return bp5_copy_constrained(mf, src, dst);
+}
+
+// ------------------------------------------------------------------------------------ rhs / norms
+template <int n>
+static int launch_rhs(bp5_mf *mf, double *b)
+{
+  const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 65535u * 16);
+  hipLaunchKernelGGL(rhs_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab_gauss, mf->n_cells, b);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+static int rhs_dispatch(bp5_mf *mf, double *b) { DISPATCH_N(launch_rhs, mf, b); }
+extern "C" int bp5_assemble_rhs(bp5_mf *mf, double *b)
+{
+  if (!mf || !b) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  HIP_TRY(hipMemsetAsync(b, 0, mf->n_local() * sizeof(double), mf->stream));
+  BP5_TRY(rhs_dispatch(mf, b));
+  if (mf->comm && mf->comm->n_ranks > 1) BP5_TRY(bp5_halo_scatter_add(mf, b));
+  return bp5_set_constrained(mf, 0.0, b);
+}
+template <int n>
+static int launch_l2(bp5_mf *mf, const double *u, double *out)
+{
+  const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 4096u);
+  hipLaunchKernelGGL(l2norm_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab_gauss, mf->n_cells, u,
+                     out);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+static int l2_dispatch(bp5_mf *mf, const double *u, double *out) { DISPATCH_N(launch_l2, mf, u, out); }
+extern "C" int bp5_l2_norm_solution(bp5_mf *mf, const double *u, double *result)
+{
+  if (!mf || !u || !result) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  HIP_TRY(hipMemsetAsync(mf->d_scalar, 0, sizeof(double), mf->stream));
+  BP5_TRY(l2_dispatch(mf, u, mf->d_scalar));
+  if (mf->comm && mf->comm->n_ranks > 1) BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_scalar, 1));
+  double s = 0.0;
+  HIP_TRY(hipMemcpyAsync(&s, mf->d_scalar, sizeof(double), hipMemcpyDeviceToHost, mf->stream));
+  HIP_TRY(hipStreamSynchronize(mf->stream));
+  *result = std::sqrt(s);
+  return BP5_OK;
+}
+
+// ------------------------------------------------------------------------------------ BLAS-1
+static inline int stream_grid(size_t n, int per_thread)
+{
+  size_t b = (n + (size_t)VB * per_thread - 1) / ((size_t)VB * per_thread);
+  return (int)std::min<size_t>(std::max<size_t>(b, 1), MAXBLK);
+}
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+extern "C" int bp5_vec_fill(bp5_mf *mf, double *v, double value, size_t n)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (!aligned16(v)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  hipLaunchKernelGGL(vec_kernel<0>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, v, (const double *)nullptr, value, 0.0, n);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_vec_axpy(bp5_mf *mf, double *y, double a, const double *x, size_t n)
+{
+  if (!mf || !y || !x) return fail(BP5_ERR_INVALID, "null argument");
+  if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  hipLaunchKernelGGL(vec_kernel<1>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, y, x, 0.0, a, n);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_vec_equ(bp5_mf *mf, double *y, double a, const double *x, size_t n)
+{
+  if (!mf || !y || !x) return fail(BP5_ERR_INVALID, "null argument");
+  if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  hipLaunchKernelGGL(vec_kernel<2>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, y, x, 0.0, a, n);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_vec_sadd(bp5_mf *mf, double *y, double s, double a, const double *x, size_t n)
+{
+  if (!mf || !y || !x) return fail(BP5_ERR_INVALID, "null argument");
+  if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  hipLaunchKernelGGL(vec_kernel<3>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, y, x, s, a, n);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+extern "C" int bp5_vec_dot(bp5_mf *mf, const double *x, const double *y, size_t n, double *result)
+{
+  if (!mf || !y || !x || !result) return fail(BP5_ERR_INVALID, "null argument");
+  if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  const int g = stream_grid(n, 2);
+  hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(VB), 0, mf->stream, x, y, n, mf->d_partials);
+  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, mf->stream, mf->d_partials, g, mf->d_scalar, (const int *)nullptr);
+  KERNEL_CHECK();
+  HIP_TRY(hipMemcpyAsync(result, mf->d_scalar, sizeof(double), hipMemcpyDeviceToHost, mf->stream));
+  HIP_TRY(hipStreamSynchronize(mf->stream));
+  return BP5_OK;
+}
+
+// ------------------------------------------------------------------------------------ RCCL
+extern "C" int bp5_comm_unique_id(char *id)
+{
+  if (!id) return fail(BP5_ERR_INVALID, "null argument");
+  static_assert(sizeof(ncclUniqueId) <= BP5_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId uid;
+  NCCL_TRY(ncclGetUniqueId(&uid));
+  memset(id, 0, BP5_UNIQUE_ID_BYTES);
+  memcpy(id, &uid, sizeof(uid));
+  return BP5_OK;
+}
+extern "C" int bp5_comm_create(const char *id, int rank, int n_ranks, bp5_comm **out)
+{
+  if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(BP5_ERR_INVALID, "bad argument");
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  bp5_comm *c = new bp5_comm;
+  c->rank = rank; c->n_ranks = n_ranks;
+  ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, uid, rank);
+  if (r != ncclSuccess) { delete c; return fail(BP5_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  *out = c;
+  return BP5_OK;
+}
+extern "C" int bp5_comm_destroy(bp5_comm *c)
+{
+  if (!c) return BP5_OK;
+  if (c->comm) ncclCommDestroy(c->comm);
+  delete c;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_set_comm(bp5_mf *mf, bp5_comm *comm)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  mf->comm = comm;
+  return BP5_OK;
+}
+extern "C" int bp5_comm_allreduce_sum(bp5_mf *mf, double *buf, size_t n)
+{
+  if (!mf || !buf) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf->comm || mf->comm->n_ranks == 1) return BP5_OK;
+  NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, mf->comm->comm, mf->stream));
+  return BP5_OK;
+}
+// ghost gather: owners send their interface values (packed through send_indices), ghosts are
+// received straight into the vector's ghost range (contiguous per neighbour)
+extern "C" int bp5_halo_gather(bp5_mf *mf, double *v)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (mf->neighbors.empty()) return BP5_OK;
+  if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
+  const uint32_t ns = mf->send_off.back();
+  if (ns) {
+    hipLaunchKernelGGL(pack_kernel, dim3((ns + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx, ns, v, mf->d_sendbuf);
+    KERNEL_CHECK();
+  }
+  NCCL_TRY(ncclGroupStart());
+  for (size_t k = 0; k < mf->neighbors.size(); ++k) {
+    const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k], rc = mf->recv_off[k + 1] - mf->recv_off[k];
+    if (sc) NCCL_TRY(ncclSend(mf->d_sendbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
+    if (rc) NCCL_TRY(ncclRecv(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  return BP5_OK;
+}
+// compress(add): ghost contributions travel back to the owners and are added; ghosts zeroed
+extern "C" int bp5_halo_scatter_add(bp5_mf *mf, double *v)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (mf->neighbors.empty()) return BP5_OK;
+  if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
+  NCCL_TRY(ncclGroupStart());
+  for (size_t k = 0; k < mf->neighbors.size(); ++k) {
+    const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k], rc = mf->recv_off[k + 1] - mf->recv_off[k];
+    if (rc) NCCL_TRY(ncclSend(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
+    if (sc) NCCL_TRY(ncclRecv(mf->d_recvbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  for (size_t k = 0; k < mf->neighbors.size(); ++k) { // per neighbour: indices distinct -> race-free, fixed order
+    const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k];
+    if (!sc) continue;
+    hipLaunchKernelGGL(unpack_add_kernel, dim3((sc + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx + mf->send_off[k], sc,
+                       mf->d_recvbuf + mf->send_off[k], v);
+    KERNEL_CHECK();
+  }
+  return bp5_halo_zero_ghosts(mf, v);
+}
+extern "C" int bp5_halo_zero_ghosts(bp5_mf *mf, double *v)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (mf->n_ghost) HIP_TRY(hipMemsetAsync(v + mf->n_owned, 0, (size_t)mf->n_ghost * sizeof(double), mf->stream));
+  return BP5_OK;
+}
+extern "C" int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src, double *dst, int zero_dst)
+{
+  if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
+  HIP_TRY(hipSetDevice(mf->device));
+  if (zero_dst) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  // stream order: ghost gather, all cells, scatter-add.  (Interior cells [0,n_interior) do not
+  // read ghosts; the overlapped 3-phase schedule of SURVEY 3.2 is a later optimisation.)
+  BP5_TRY(bp5_halo_gather(mf, src));
+  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells));
+  BP5_TRY(bp5_halo_scatter_add(mf, dst));
+  BP5_TRY(bp5_halo_zero_ghosts(mf, src));
+  return bp5_copy_constrained(mf, src, dst);
+}
+
+// ------------------------------------------------------------------------------------ events
+extern "C" int bp5_event_create(bp5_event **out)
+{
+  if (!out) return fail(BP5_ERR_INVALID, "null argument");
+  bp5_event *e = new bp5_event;
+  hipError_t r = hipEventCreate(&e->ev);
+  if (r != hipSuccess) { delete e; return fail(BP5_ERR_HIP, hipGetErrorString(r)); }
+  *out = e;
+  return BP5_OK;
+}
+extern "C" int bp5_event_record(bp5_mf *mf, bp5_event *ev)
+{
+  if (!mf || !ev) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipEventRecord(ev->ev, mf->stream));
+  return BP5_OK;
+}
+extern "C" int bp5_event_elapsed_ms(bp5_event *a, bp5_event *b, double *ms)
+{
+  if (!a || !b || !ms) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipEventSynchronize(b->ev));
+  float f = 0.f;
+  HIP_TRY(hipEventElapsedTime(&f, a->ev, b->ev));
+  *ms = f;
+  return BP5_OK;
+}
+extern "C" int bp5_event_destroy(bp5_event *e)
+{
+  if (!e) return BP5_OK;
+  hipEventDestroy(e->ev);
+  delete e;
+  return BP5_OK;
+}
+
+// ------------------------------------------------------------------------------------ CG
+static int ensure_ws(bp5_mf *mf)
+{
+  if (mf->ws_g) return BP5_OK;
+  const size_t nb = std::max<size_t>(mf->n_local(), 2) * sizeof(double);
+  HIP_TRY(hipMalloc((void **)&mf->ws_g, nb));
+  HIP_TRY(hipMalloc((void **)&mf->ws_d, nb));
+  HIP_TRY(hipMalloc((void **)&mf->ws_h, nb));
+  HIP_TRY(hipMemset(mf->ws_g, 0, nb));
+  HIP_TRY(hipMemset(mf->ws_d, 0, nb));
+  HIP_TRY(hipMemset(mf->ws_h, 0, nb));
+  return BP5_OK;
+}
+
+struct ApplyProfile {
+  bp5_mf *mf;
+  bool on;
+  int used = 0;
+  int begin()
+  {
+    if (!on) return BP5_OK;
+    if ((size_t)used + 2 > mf->ev_pool.size()) {
+      for (int k = 0; k < 2; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
+    }
+    HIP_TRY(hipEventRecord(mf->ev_pool[used], mf->stream));
+    return BP5_OK;
+  }
+  int end()
+  {
+    if (!on) return BP5_OK;
+    HIP_TRY(hipEventRecord(mf->ev_pool[used + 1], mf->stream));
+    used += 2;
+    return BP5_OK;
+  }
+};
+
+// A.vmult(h, d) inside the solvers: dst already zero on entry when zeroed == true
+static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof)
+{
+  const bool dist = mf->comm && mf->comm->n_ranks > 1;
+  if (zero) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  if (dist) BP5_TRY(bp5_halo_gather(mf, src));
+  BP5_TRY(prof.begin());
+  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells));
+  BP5_TRY(prof.end());
+  if (dist) { BP5_TRY(bp5_halo_scatter_add(mf, dst)); BP5_TRY(bp5_halo_zero_ghosts(mf, src)); }
+  return bp5_copy_constrained(mf, src, dst);
+}
+
+static int poll_state(bp5_mf *mf)
+{
+  HIP_TRY(hipMemcpyAsync(mf->h_st, mf->d_st, ST_COUNT * sizeof(int), hipMemcpyDeviceToHost, mf->stream));
+  HIP_TRY(hipMemcpyAsync(mf->h_sc, mf->d_sc, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, mf->stream));
+  HIP_TRY(hipStreamSynchronize(mf->stream));
+  return BP5_OK;
+}
+
+extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, const double *b, double *x, const bp5_cg_params *prm,
+                            bp5_cg_result *res)
+{
+  if (!mf || !coef || !b || !x || !prm || !res) return fail(BP5_ERR_INVALID, "null argument");
+  if (prm->max_iter < 0) return fail(BP5_ERR_INVALID, "max_iter < 0");
+  if (prm->variant != BP5_CG_PLAIN && prm->variant != BP5_CG_MERGED) return fail(BP5_ERR_INVALID, "unknown CG variant");
+  if (!aligned16(b) || !aligned16(x) || (diag && !aligned16(diag))) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(mf->device));
+  BP5_TRY(ensure_ws(mf));
+  const size_t n = mf->n_owned;
+  const int grid2 = stream_grid(n, 2), grid1 = stream_grid(n, 1);
+  hipStream_t s = mf->stream;
+  double *g = mf->ws_g, *d = mf->ws_d, *h = mf->ws_h;
+  ApplyProfile prof{mf, prm->profile != 0};
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  // scalars: tolerance + iteration cap
+  mf->h_sc[SC_TOL] = prm->abs_tol;
+  HIP_TRY(hipMemcpyAsync(mf->d_sc + SC_TOL, mf->h_sc + SC_TOL, sizeof(double), hipMemcpyHostToDevice, s));
+  mf->h_st[ST_MAXIT] = prm->max_iter;
+  HIP_TRY(hipMemcpyAsync(mf->d_st + ST_MAXIT, mf->h_st + ST_MAXIT, sizeof(int), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s)); // pinned staging words are reused below
+  HIP_TRY(hipEventRecord(ev0, s));
+  const bool plain = prm->variant == BP5_CG_PLAIN;
+  const int check = prm->check_every;
+  int status = BP5_OK;
+
+  if (plain) {
+    // g = -b, d = -D g, x = 0   (x0 = 0 short-circuit, bp5/solver.h:375-381)
+    hipLaunchKernelGGL(cg_init_kernel, dim3(grid1), dim3(VB), 0, s, b, diag, x, g, d, n, mf->d_partials);
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
+    KERNEL_CHECK();
+    BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
+    hipLaunchKernelGGL(cg_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+    KERNEL_CHECK();
+    for (int it = 1; it <= prm->max_iter; ++it) {
+      BP5_TRY(solver_vmult(mf, coef, d, h, true, prof));
+      hipLaunchKernelGGL(dot_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials);
+      hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_DH, mf->d_st);
+      KERNEL_CHECK();
+      BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_DH, 1));
+      hipLaunchKernelGGL(cg_update_kernel, dim3(grid2), dim3(VB), 0, s, x, g, d, h, diag, n, mf->d_sc, mf->d_st, mf->d_partials);
+      hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_GG, mf->d_st);
+      KERNEL_CHECK();
+      BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
+      hipLaunchKernelGGL(cg_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+      hipLaunchKernelGGL(cg_direction_kernel, dim3(grid2), dim3(VB), 0, s, d, g, diag, n, mf->d_sc, mf->d_st);
+      KERNEL_CHECK();
+      if (check > 0 && it % check == 0 && it < prm->max_iter) {
+        BP5_TRY(poll_state(mf));
+        if (mf->h_st[ST_DONE]) break;
+      }
+    }
+  } else {
+    // SolverCGFullMerge: g == r, d == p, h == v
+    hipLaunchKernelGGL(cgm_init_kernel, dim3(grid1), dim3(VB), 0, s, b, x, g, d, h, n, mf->d_partials);
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
+    KERNEL_CHECK();
+    BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
+    hipLaunchKernelGGL(cgm_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+    KERNEL_CHECK();
+    int it = 1;
+    for (; it <= prm->max_iter; ++it) {
+      if (it == 1) hipLaunchKernelGGL(cgm_update_kernel<0>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      else if (it % 2 == 0) hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      else hipLaunchKernelGGL(cgm_update_kernel<2>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      KERNEL_CHECK();
+      BP5_TRY(solver_vmult(mf, coef, d, h, false, prof)); // v was zeroed by the update (do_zero_out = false, bp5/step-64.cu:483)
+      hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid1), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
+      hipLaunchKernelGGL(finalize_kernel<7>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_R0, mf->d_st);
+      KERNEL_CHECK();
+      BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
+      hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+      KERNEL_CHECK();
+      if (check > 0 && it % check == 0 && it < prm->max_iter) {
+        BP5_TRY(poll_state(mf));
+        if (mf->h_st[ST_DONE]) break;
+      }
+    }
+    // epilogue x update (solver.h:510-526) runs inside the next update kernel
+    hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+    hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+    KERNEL_CHECK();
+  }
+  HIP_TRY(hipEventRecord(ev1, s));
+  BP5_TRY(poll_state(mf));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
+  res->iterations = mf->h_st[ST_ITER];
+  res->residual = mf->h_sc[SC_RES];
+  res->initial_residual = mf->h_sc[SC_RES0];
+  res->solve_ms = ms;
+  res->apply_ms_avg = 0.0;
+  res->apply_launches = prof.used / 2;
+  if (prof.on && prof.used) {
+    double tot = 0.0;
+    for (int k = 0; k < prof.used; k += 2) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, mf->ev_pool[k], mf->ev_pool[k + 1]));
+      tot += t;
+    }
+    res->apply_ms_avg = tot / (prof.used / 2);
+  }
+  if (mf->h_st[ST_BREAKDOWN]) status = fail(BP5_ERR_BREAKDOWN, "CG breakdown: p.Ap is zero or NaN");
+  return status;
+}

@@ -1,0 +1,264 @@
+"""Host-side mirror of the reference's operator/solver interface for the BP5 path, on top of the
+C ABI (include/bp5.h).  Names, argument meaning and error behaviour follow the reference:
+
+  MatrixFree ............. CUDAWrappers::MatrixFree<3,double> as used at bp5/step-64.cu:234-275
+  PoissonOperator ........ bp5/step-64.cu:198-276 (vmult, initialize_dof_vector, do_zero_out)
+  DiagonalMatrix ......... bp5/step-64.cu:428-432 (get_vector)
+  IterationNumberControl . bp5/step-64.cu:443-445 (last_step)
+  SolverCG ............... deal.II SolverCG, call site bp5/step-64.cu:446-453
+  SolverCGFullMerge ...... bp5/solver.h:16-30,343-542 (x-update schedule fixed)
+
+Vectors are torch float64 CUDA tensors of n_owned + n_ghost entries (torch is plumbing for
+device memory / streams / the process group only -- no torch op is on the hot path)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BP5Error, CG_MERGED, CG_PLAIN, COEF_ONE, QUAD_GAUSS
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t, n_min=0):
+    torch = _torch()
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise BP5Error(1, "expected a contiguous float64 CUDA tensor")
+    if t.numel() < n_min:
+        raise BP5Error(1, f"vector has {t.numel()} entries, need {n_min}")
+    return C.c_void_p(t.data_ptr())
+
+
+class Communicator:
+    """RCCL communicator, one rank per GPU.  The 128-byte unique id is created on rank 0 and
+    broadcast by the host (here: torch.distributed, any backend)."""
+
+    def __init__(self, rank=0, n_ranks=1, unique_id=None):
+        L = _lib.lib()
+        if unique_id is None:
+            buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+            _lib.check(L.bp5_comm_unique_id(buf))
+            unique_id = buf.raw
+        self.rank, self.n_ranks = rank, n_ranks
+        self._h = C.c_void_p()
+        _lib.check(L.bp5_comm_create(C.c_char_p(unique_id), rank, n_ranks, C.byref(self._h)))
+
+    @classmethod
+    def from_torch_distributed(cls):
+        import torch.distributed as dist
+        rank, n = dist.get_rank(), dist.get_world_size()
+        box = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+            _lib.check(_lib.lib().bp5_comm_unique_id(buf))
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0)
+        return cls(rank, n, box[0])
+
+    def close(self):
+        if self._h:
+            _lib.lib().bp5_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class MatrixFree:
+    """== CUDAWrappers::MatrixFree<3,double>; reinit uploads the flat per-cell arrays."""
+
+    def __init__(self):
+        self._h = None
+        self.mesh = None
+
+    def reinit(self, mesh, quadrature=QUAD_GAUSS, coefficient=COEF_ONE, device=0, stream=None, comm=None):
+        """== mf_data.reinit(mapping, dof_handler, constraints, quad, additional_data),
+        bp5/step-64.cu:234-248."""
+        torch = _torch()
+        L = _lib.lib()
+        self.mesh, self.quadrature, self.coefficient, self.device = mesh, quadrature, coefficient, device
+        if stream is None:
+            stream = torch.cuda.current_stream(device).cuda_stream
+        d = _lib.MFDesc()
+        d.dim, d.degree, d.quadrature, d.coefficient = 3, mesh.degree, quadrature, coefficient
+        d.n_cells, d.n_interior_cells, d.n_owned, d.n_ghost = mesh.n_cells, mesh.n_interior_cells, mesh.n_owned, mesh.n_ghost
+        keep = [np.ascontiguousarray(mesh.l2g, dtype=np.uint32), np.ascontiguousarray(mesh.coords, dtype=np.float64),
+                np.ascontiguousarray(mesh.constrained, dtype=np.uint32), np.ascontiguousarray(mesh.neighbor_rank, dtype=np.int32),
+                np.ascontiguousarray(mesh.send_offsets, dtype=np.uint32), np.ascontiguousarray(mesh.send_indices, dtype=np.uint32),
+                np.ascontiguousarray(mesh.recv_offsets, dtype=np.uint32)]
+        d.local_to_global_host, d.node_coords_host, d.constrained_host = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data
+        d.n_constrained = keep[2].size
+        d.n_neighbors = int(mesh.n_neighbors)
+        d.neighbor_rank_host, d.send_offsets_host = keep[3].ctypes.data, keep[4].ctypes.data
+        d.send_indices_host, d.recv_offsets_host = keep[5].ctypes.data, keep[6].ctypes.data
+        d.device, d.stream = device, stream
+        h = C.c_void_p()
+        _lib.check(L.bp5_mf_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.n_owned, self.n_ghost, self.n_local = mesh.n_owned, mesh.n_ghost, mesh.n_owned + mesh.n_ghost
+        self.comm = comm
+        if comm is not None:
+            _lib.check(L.bp5_mf_set_comm(h, comm._h))
+        return self
+
+    # -- handle plumbing
+    @property
+    def handle(self):
+        if not self._h:
+            raise BP5Error(1, "MatrixFree.reinit has not been called")
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.lib().bp5_mf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(_lib.lib().bp5_mf_sync(self.handle))
+
+    def set_apply_variant(self, v):
+        _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
+
+    # -- reference API
+    def initialize_dof_vector(self, vec=None):
+        """== mf_data.initialize_dof_vector(vec), bp5/step-64.cu:214: owned + ghost storage."""
+        torch = _torch()
+        return torch.zeros(self.n_local, dtype=torch.float64, device=f"cuda:{self.device}")
+
+    def coef_size(self):
+        n = C.c_size_t()
+        _lib.check(_lib.lib().bp5_mf_coef_size(self.handle, C.byref(n)))
+        return n.value
+
+    def evaluate_coefficients(self, coef=None):
+        """== mf_data.evaluate_coefficients(JacobianFunctor), bp5/step-64.cu:256-258."""
+        torch = _torch()
+        if coef is None:
+            coef = torch.empty(max(self.coef_size(), 1), dtype=torch.float64, device=f"cuda:{self.device}")
+        _lib.check(_lib.lib().bp5_mf_compute_merged_metric(self.handle, _ptr(coef, self.coef_size())))
+        return coef
+
+    def coef_reference_layout(self, coef):
+        torch = _torch()
+        out = torch.empty_like(coef)
+        _lib.check(_lib.lib().bp5_mf_metric_to_reference_layout(self.handle, _ptr(coef), _ptr(out)))
+        return out
+
+    def cell_loop(self, coef, src, dst, cell_begin=0, cell_end=None):
+        """== mf_data.cell_loop(LocalPoissonOperator, src, dst), bp5/step-64.cu:274 (one range)."""
+        if cell_end is None:
+            cell_end = self.mesh.n_cells
+        _lib.check(_lib.lib().bp5_apply_cells(self.handle, _ptr(coef), _ptr(src, self.n_local), _ptr(dst, self.n_local),
+                                              cell_begin, cell_end))
+
+    def copy_constrained_values(self, src, dst):
+        _lib.check(_lib.lib().bp5_copy_constrained(self.handle, _ptr(src, self.n_local), _ptr(dst, self.n_local)))
+
+    def set_constrained_values(self, value, dst):
+        _lib.check(_lib.lib().bp5_set_constrained(self.handle, float(value), _ptr(dst, self.n_local)))
+
+    def get_data(self, color=0):
+        d = _lib.MFData()
+        _lib.check(_lib.lib().bp5_mf_get_data(self.handle, color, C.byref(d)))
+        return d
+
+
+class PoissonOperator:
+    """== BP5::PoissonOperator<3,fe_degree>, bp5/step-64.cu:198-276."""
+
+    def __init__(self, mesh, quadrature=QUAD_GAUSS, coefficient=COEF_ONE, device=0, comm=None, stream=None):
+        self.mf_data = MatrixFree().reinit(mesh, quadrature, coefficient, device, stream, comm)
+        self.coef = self.mf_data.evaluate_coefficients()
+        self.n_owned_cells = mesh.n_cells
+        self.do_zero_out = True                      # bp5/step-64.cu:223,232
+        self.distributed = comm is not None and comm.n_ranks > 1
+
+    def initialize_dof_vector(self, vec=None):
+        return self.mf_data.initialize_dof_vector(vec)
+
+    def vmult(self, dst, src):
+        """dst = [0 +] A src; dst[c] = src[c] on Dirichlet DoFs (bp5/step-64.cu:263-276)."""
+        L, mf = _lib.lib(), self.mf_data
+        fn = L.bp5_apply_distributed if self.distributed else L.bp5_apply
+        _lib.check(fn(mf.handle, _ptr(self.coef), _ptr(src, mf.n_local), _ptr(dst, mf.n_local), 1 if self.do_zero_out else 0))
+
+    def assemble_rhs(self):
+        b = self.initialize_dof_vector()
+        _lib.check(_lib.lib().bp5_assemble_rhs(self.mf_data.handle, _ptr(b)))
+        return b
+
+    def l2_norm_solution(self, u):
+        r = C.c_double()
+        _lib.check(_lib.lib().bp5_l2_norm_solution(self.mf_data.handle, _ptr(u, self.mf_data.n_local), C.byref(r)))
+        return r.value
+
+
+class DiagonalMatrix:
+    """== DiagonalMatrix<Vector>; `None` vector == identity (the reference sets it to 1,
+    bp5/step-64.cu:432, and still streams it; here identity costs no bytes)."""
+
+    def __init__(self, vector=None):
+        self._v = vector
+
+    def get_vector(self):
+        return self._v
+
+
+class SolverControl:
+    def __init__(self, max_steps=100, tolerance=1e-10):
+        self.max_steps, self.tolerance = int(max_steps), float(tolerance)
+        self._last_step, self._last_value, self._initial_value = 0, float("nan"), float("nan")
+        self.solve_ms = self.apply_ms_avg = 0.0
+        self.apply_launches = 0
+
+    def last_step(self):
+        return self._last_step
+
+    def last_value(self):
+        return self._last_value
+
+    def initial_value(self):
+        return self._initial_value
+
+
+class IterationNumberControl(SolverControl):
+    """Stops at max_steps or when the residual drops below tolerance, reports success either way
+    (bp5/step-64.cu:443-445)."""
+
+
+class _SolverBase:
+    variant = CG_PLAIN
+
+    def __init__(self, control, check_every=0, profile=False):
+        self.control, self.check_every, self.profile = control, check_every, profile
+
+    def solve(self, A, x, b, preconditioner=None):
+        """== cg.solve(A, x, b, preconditioner), bp5/step-64.cu:450-453,492-495.  x0 = 0."""
+        mf = A.mf_data
+        diag = preconditioner.get_vector() if preconditioner is not None else None
+        prm = _lib.CGParams(self.variant, self.control.max_steps, self.control.tolerance, self.check_every,
+                            1 if self.profile else 0)
+        res = _lib.CGResult()
+        status = _lib.lib().bp5_cg_solve(mf.handle, _ptr(A.coef), _ptr(diag, mf.n_owned) if diag is not None else None,
+                                         _ptr(b, mf.n_local), _ptr(x, mf.n_local), C.byref(prm), C.byref(res))
+        c = self.control
+        c._last_step, c._last_value, c._initial_value = res.iterations, res.residual, res.initial_residual
+        c.solve_ms, c.apply_ms_avg, c.apply_launches = res.solve_ms, res.apply_ms_avg, res.apply_launches
+        _lib.check(status)
+        return res
+
+
+class SolverCG(_SolverBase):
+    variant = CG_PLAIN
+
+
+class SolverCGFullMerge(_SolverBase):
+    variant = CG_MERGED

@@ -1,0 +1,253 @@
+/* bp5.h -- C ABI of the MI355X-native BP5 matrix-free operator + CG hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one piece of the reference's
+ * (peterrum/deal-and-ceed-on-gpu) hot path, cited as file:line under the reference root.  The
+ * reference has no FFI of its own (it is C++ calling deal.II templates); a maintainer binds
+ * these symbols from the C++ host code as shown in INTEGRATION.md, or uses the header-only
+ * facade include/bp5_dealii_facade.hpp which re-creates the deal.II class names on top of them.
+ *
+ * Conventions
+ *   - every function returns an int status (BP5_OK == 0); no exception crosses the boundary
+ *     (the reference throws: AssertThrow/AssertCuda, bp5/solver.h:396-397,539-540);
+ *   - pointers are DEVICE pointers unless the parameter name ends in `_host`;
+ *   - handles are opaque, one per device; calls on one handle are not thread-safe;
+ *   - all device work is enqueued on the handle's stream (bp5_mf_set_stream) and is
+ *     asynchronous unless stated otherwise; nothing allocates inside the hot loop;
+ *   - FP64 arithmetic, 32-bit DoF indices (types::global_dof_index, bp5/fe_evaluation_gl.h:84);
+ *   - vectors are plain arrays of n_owned + n_ghost doubles, owned range first
+ *     (LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA>, bp5/step-64.cu:321-323).
+ */
+#ifndef BP5_H
+#define BP5_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* status codes                                                                                */
+enum {
+  BP5_OK = 0,
+  BP5_ERR_INVALID = 1,        /* bad argument / unsupported degree                             */
+  BP5_ERR_HIP = 2,            /* a HIP runtime call failed (AssertCuda, bp5/solver.h:396-397)  */
+  BP5_ERR_NO_DEVICE = 3,      /* no gfx950 device visible: there is NO CPU fallback            */
+  BP5_ERR_RCCL = 4,           /* an RCCL call failed                                           */
+  BP5_ERR_UNSUPPORTED = 5,    /* e.g. hanging-node constraint mask != 0                        */
+  BP5_ERR_BREAKDOWN = 6,      /* CG breakdown: p.Ap == 0 or NaN (ExcDivideByZero, solver.h:501)*/
+  BP5_ERR_NO_CONVERGENCE = 7  /* SolverControl::NoConvergence, bp5/solver.h:539-540            */
+};
+const char *bp5_strerror(int status);
+const char *bp5_last_error(void); /* detail of the last failure on this thread */
+
+enum { BP5_QUAD_GAUSS = 0, /* QGauss<1>(p+1), bp5/step-64.cu:246 (reference default) */
+       BP5_QUAD_GLL = 1    /* QGaussLobatto<1>(p+1), bp5/step-64.cu:244 (COLLOCATION) */ };
+
+enum { BP5_COEF_ONE = 0,   /* kappa == 1: the reference folds only JxW, bp5/step-64.cu:107-113 */
+       BP5_COEF_STEP64 = 1 /* kappa = 10/(0.05+2|x|^2), step-64/step-64.cu:117 */ };
+
+#define BP5_MAX_DEGREE 8
+
+/* ------------------------------------------------------------------------------------------ */
+/* host-only helpers (run without a GPU)                                                       */
+
+/* 1-D data of FE_Q(degree) on GLL nodes with the chosen quadrature, all on [0,1]:
+ * nodes[n], pts[n], w[n], N[q*n+i] = phi_i(x_q), D[q*n+i] = phi_i'(x_q), n = degree+1.
+ * Replaces the shape_values/shape_gradients tables MatrixFree::reinit builds
+ * (call site bp5/step-64.cu:243-248). */
+int bp5_shape_tables(int degree, int quadrature, double *nodes_host, double *pts_host, double *w_host,
+                     double *N_host, double *D_host);
+
+/* Structured hex-mesh generator standing in for GridGenerator::subdivided_hyper_rectangle +
+ * refine_global + DoFHandler::distribute_dofs + zero Dirichlet constraints
+ * (bp5/step-64.cu:341-358, 629-663); slab partition along z replaces the p4est partition. */
+typedef struct bp5_mesh bp5_mesh;
+typedef struct {
+  int degree;          /* p */
+  uint32_t cells[3];   /* global number of cells per direction */
+  double h;            /* cell side (reference: 2^-refine) */
+  double deform_amp;   /* 0 = cubes; >0 = smooth boundary-preserving sine displacement */
+  int rank, n_ranks;   /* z-slab decomposition; interface planes owned by the lower rank */
+} bp5_mesh_desc;
+
+typedef struct {
+  int degree;
+  uint32_t n_cells;           /* locally owned cells                                            */
+  uint32_t n_interior_cells;  /* cells [0,n_interior_cells) touch no ghost DoF                  */
+  uint32_t n_owned, n_ghost;  /* local DoFs: owned first, then ghosts                           */
+  uint64_t n_global_dofs;
+  uint32_t global_dofs_per_dir[3];
+  const uint32_t *local_to_global_host; /* [n_cells*(p+1)^3], local indices, i + n(j + n k)     */
+  const double *node_coords_host;       /* [n_owned+n_ghost][3]                                 */
+  const uint64_t *global_ids_host;      /* [n_owned+n_ghost] lexicographic global DoF id        */
+  const uint32_t *constrained_host;     /* local indices of Dirichlet DoFs (owned + ghost)      */
+  uint32_t n_constrained;
+  /* halo plan (Utilities::MPI::Partitioner): per neighbour, owned indices to send for the
+   * ghost gather, and the contiguous ghost range received from it */
+  int n_neighbors;
+  const int *neighbor_rank_host;        /* [n_neighbors]                                        */
+  const uint32_t *send_offsets_host;    /* [n_neighbors+1] into send_indices                    */
+  const uint32_t *send_indices_host;    /* owned local indices                                  */
+  const uint32_t *recv_offsets_host;    /* [n_neighbors+1] offsets into the ghost range         */
+} bp5_mesh_view;
+
+int bp5_mesh_create_brick(const bp5_mesh_desc *desc, bp5_mesh **out);
+int bp5_mesh_view_get(const bp5_mesh *mesh, bp5_mesh_view *out);
+void bp5_mesh_destroy(bp5_mesh *mesh);
+
+/* ------------------------------------------------------------------------------------------ */
+/* device + vectors                                                                            */
+int bp5_device_count(int *count);
+int bp5_vec_alloc(size_t n, double **out);            /* hipMalloc, zero-filled                 */
+int bp5_vec_free(double *v);
+int bp5_copy_h2d(void *dst, const void *src_host, size_t bytes);   /* synchronous               */
+int bp5_copy_d2h(void *dst_host, const void *src, size_t bytes);   /* synchronous               */
+
+/* ------------------------------------------------------------------------------------------ */
+/* matrix-free engine: CUDAWrappers::MatrixFree<3,double> as the reference uses it             */
+typedef struct bp5_mf bp5_mf;
+
+typedef struct {
+  int dim;                 /* must be 3                                                         */
+  int degree;              /* 1..BP5_MAX_DEGREE                                                 */
+  int quadrature;          /* BP5_QUAD_*                                                        */
+  int coefficient;         /* BP5_COEF_*                                                        */
+  uint32_t n_cells, n_interior_cells, n_owned, n_ghost;
+  const uint32_t *local_to_global_host;
+  const double *node_coords_host;       /* MappingQGeneric(degree) through the FE_Q nodes,
+                                           bp5/step-64.cu:234                                   */
+  const uint32_t *constrained_host;
+  uint32_t n_constrained;
+  int n_neighbors;
+  const int *neighbor_rank_host;
+  const uint32_t *send_offsets_host, *send_indices_host, *recv_offsets_host;
+  int device;              /* HIP device ordinal                                                */
+  void *stream;            /* hipStream_t or NULL (= a private non-blocking stream)             */
+} bp5_mf_desc;
+
+/* == MatrixFree::reinit(mapping, dof_handler, constraints, quad, additional_data),
+ *    bp5/step-64.cu:234-248.  Uploads the flat arrays; computes nothing yet. */
+int bp5_mf_create(const bp5_mf_desc *desc, bp5_mf **out);
+int bp5_mf_destroy(bp5_mf *mf);
+int bp5_mf_set_stream(bp5_mf *mf, void *hip_stream);
+int bp5_mf_sync(bp5_mf *mf); /* hipStreamSynchronize */
+
+/* number of doubles of the merged-metric array: 6 * n_cells * (p+1)^3  (bp5/step-64.cu:253-254) */
+int bp5_mf_coef_size(const bp5_mf *mf, size_t *n_doubles);
+
+/* == mf_data.evaluate_coefficients(JacobianFunctor), bp5/step-64.cu:84-114,256-258:
+ *    coef_c = kappa * JxW * (K K^T)_c, c in {00,11,22,01,02,12}.
+ *    Device layout (this library's own; the reference's is [c][cell][q]):
+ *      coef[c*n_cells*nq + cell*nq + qi*n*n + (qj + n*qk)]
+ *    i.e. q-points permuted so that the x index is slowest inside a cell. */
+int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef);
+/* permute to the reference layout [c][cell][qi + n(qj + n qk)] (tests / interop) */
+int bp5_mf_metric_to_reference_layout(bp5_mf *mf, const double *coef, double *coef_ref);
+
+/* MatrixFree::Data mirror (bp5/fe_evaluation_gl.h:112-120, bp5/step-64.cu:94-97):
+ * the unmerged geometry inv_jacobian (9 SoA planes) and JxW with deal.II's padding.
+ * Arrays are created on first request. */
+typedef struct {
+  const uint32_t *local_to_global; /* [n_cells*padding_length]                                  */
+  const double *inv_jacobian;      /* [9][n_cells*padding_length], plane d*3+e = d xi_d/d x_e   */
+  const double *JxW;               /* [n_cells*padding_length]                                  */
+  const double *q_points;          /* [3][n_cells*padding_length]                               */
+  const uint32_t *constraint_mask; /* [n_cells], all zero (conforming meshes only)              */
+  uint32_t n_cells, padding_length, row_start;
+  int use_coloring;
+} bp5_mf_data;
+int bp5_mf_get_data(bp5_mf *mf, int color, bp5_mf_data *out);
+
+/* == PoissonOperator::vmult(dst, src), bp5/step-64.cu:263-276:
+ *    [dst = 0 if zero_dst] ; dst += sum_cells P^T B^T S B P src ; dst[c] = src[c] on Dirichlet DoFs.
+ *    Single-rank form (no halo exchange). */
+int bp5_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, int zero_dst);
+/* pieces, for hosts that overlap the halo exchange themselves (MatrixFree::cell_loop,
+ * bp5/step-64.cu:274): cell range [cell_begin, cell_end) only, no zeroing, no Dirichlet copy */
+int bp5_apply_cells(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t cell_begin,
+                    uint32_t cell_end);
+/* == mf_data.copy_constrained_values(src, dst), bp5/step-64.cu:275 */
+int bp5_copy_constrained(bp5_mf *mf, const double *src, double *dst);
+/* == MatrixFree::set_constrained_values(val, dst) [upstream] */
+int bp5_set_constrained(bp5_mf *mf, double value, double *dst);
+
+/* kernel variant selection for the fused operator (tuning / A-B tests):
+ * 0 = library default for the degree */
+int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
+
+/* b_i = int phi_i with Gauss(p+1), constrained rows 0 (assemble_rhs, bp5/step-64.cu:372-418) */
+int bp5_assemble_rhs(bp5_mf *mf, double *b);
+/* ||u_h||_L2 by Gauss(p+1) quadrature (output_results, bp5/step-64.cu:602-616); synchronous */
+int bp5_l2_norm_solution(bp5_mf *mf, const double *u, double *result_host);
+
+/* ------------------------------------------------------------------------------------------ */
+/* vector BLAS-1 used by the solvers (LinearAlgebra::distributed::Vector surface,
+ * bp5/solver.h:369-382,417-421,511,528).  n = number of OWNED entries.                        */
+int bp5_vec_fill(bp5_mf *mf, double *v, double value, size_t n);
+int bp5_vec_axpy(bp5_mf *mf, double *y, double a, const double *x, size_t n);              /* y += a x   (add)  */
+int bp5_vec_equ(bp5_mf *mf, double *y, double a, const double *x, size_t n);               /* y  = a x   (equ)  */
+int bp5_vec_sadd(bp5_mf *mf, double *y, double s, double a, const double *x, size_t n);    /* y = s y + a x     */
+int bp5_vec_dot(bp5_mf *mf, const double *x, const double *y, size_t n, double *result_host); /* synchronous, local */
+
+/* ------------------------------------------------------------------------------------------ */
+/* communication: one rank per GPU, RCCL over xGMI                                             */
+typedef struct bp5_comm bp5_comm;
+#define BP5_UNIQUE_ID_BYTES 128
+int bp5_comm_unique_id(char *id_host /*[BP5_UNIQUE_ID_BYTES]*/);    /* rank 0; broadcast by the host */
+int bp5_comm_create(const char *id_host, int rank, int n_ranks, bp5_comm **out);
+int bp5_comm_destroy(bp5_comm *comm);
+int bp5_mf_set_comm(bp5_mf *mf, bp5_comm *comm);
+/* sum-allreduce of n doubles in place on the handle's stream
+ * (replaces cudaMemcpy D2H + MPI_Allreduce, bp5/solver.h:488-494) */
+int bp5_comm_allreduce_sum(bp5_mf *mf, double *buf, size_t n);
+/* == src.update_ghost_values_start/finish, dst.compress_start/finish(add), zero_out_ghosts
+ *    (inside cell_loop, bp5/step-64.cu:274) */
+int bp5_halo_gather(bp5_mf *mf, double *v);
+int bp5_halo_scatter_add(bp5_mf *mf, double *v);
+int bp5_halo_zero_ghosts(bp5_mf *mf, double *v);
+/* distributed vmult with the reference's 3-phase overlap */
+int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src, double *dst, int zero_dst);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Krylov solvers                                                                              */
+enum { BP5_CG_PLAIN = 0,  /* deal.II SolverCG (bp5/step-64.cu:446-453): the parity target      */
+       BP5_CG_MERGED = 1  /* SolverCGFullMerge (bp5/solver.h:343-542), x schedule fixed         */ };
+
+typedef struct {
+  int variant;       /* BP5_CG_*                                                                */
+  int max_iter;      /* IterationNumberControl(max_iter, abs_tol), bp5/step-64.cu:443-445       */
+  double abs_tol;    /* stop when ||r|| <= abs_tol                                              */
+  int check_every;   /* host looks at the device-side convergence flag every k iterations
+                        (0 = only at the end); the iterate is frozen on device at convergence
+                        either way, so the result does not depend on it                         */
+  int profile;       /* 1 = bracket every operator launch with HIP events                       */
+} bp5_cg_params;
+
+typedef struct {
+  int iterations;          /* SolverControl::last_step()                                        */
+  double residual;         /* last ||r||                                                        */
+  double initial_residual;
+  double solve_ms;         /* HIP-event time of the whole solve on the stream                   */
+  double apply_ms_avg;     /* profile=1: average duration of one operator launch (cell kernel)  */
+  int apply_launches;
+} bp5_cg_result;
+
+/* == cg.solve(A, x, b, preconditioner) with DiagonalMatrix (bp5/step-64.cu:446-453,488-495).
+ *    diag may be NULL (== 1, bp5/step-64.cu:432).  x is overwritten (x0 = 0, bp5/step-64.cu:449).
+ *    Returns BP5_OK also when max_iter is reached (IterationNumberControl reports success). */
+int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, const double *b, double *x,
+                 const bp5_cg_params *params, bp5_cg_result *result_host);
+
+/* event helpers so a host in another language can time on the handle's stream */
+typedef struct bp5_event bp5_event;
+int bp5_event_create(bp5_event **out);
+int bp5_event_record(bp5_mf *mf, bp5_event *ev);
+int bp5_event_elapsed_ms(bp5_event *start, bp5_event *stop, double *ms_host); /* synchronises on stop */
+int bp5_event_destroy(bp5_event *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BP5_H */

@@ -1,0 +1,114 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/bp5.h declares,
+its host-only entry points agree with the oracle, and compute fails loudly without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import bp5_oracle as O
+import bp5_pkg
+
+pkg = bp5_pkg.load()
+
+
+def test_library_exports_every_header_symbol():
+    L = pkg.lib()
+    assert len(pkg.HEADER_SYMBOLS) >= 40
+    for s in pkg.HEADER_SYMBOLS:
+        assert hasattr(L, s), s
+    # and the binding declares a prototype for each of them
+    assert set(pkg.HEADER_SYMBOLS) == set(L._protos)
+
+
+@pytest.mark.parametrize("p", range(1, 9))
+@pytest.mark.parametrize("quad", [0, 1])
+def test_shape_tables_match_oracle(p, quad):
+    a = pkg.shape_tables(p, quad)
+    b = O.shape_tables(p, quad)
+    for x, y in zip(a, b):
+        assert np.allclose(x, y, atol=1e-13, rtol=1e-13)
+    # bitwise (anti)symmetry the kernels rely on
+    N, D = a[3], a[4]
+    assert np.array_equal(N, N[::-1, ::-1]) and np.array_equal(D, -D[::-1, ::-1])
+
+
+def test_shape_tables_rejects_bad_degree():
+    from deal_and_ceed_on_gpu_amd import _lib
+    assert pkg.lib().bp5_shape_tables(0, 0, None, None, None, None, None) == 1
+    assert pkg.lib().bp5_shape_tables(9, 0, None, None, None, None, None) == 1
+    assert pkg.lib().bp5_shape_tables(3, 7, None, None, None, None, None) == 1
+    assert b"quadrature" in pkg.lib().bp5_last_error()
+
+
+@pytest.mark.parametrize("p,cells,amp", [(1, (2, 3, 2), 0.0), (2, (8, 8, 8), 0.0), (4, (3, 2, 4), 0.05), (7, (2, 2, 2), 0.03)])
+def test_mesh_matches_oracle_mesh(p, cells, amp):
+    m = pkg.BrickMesh(p, cells, h=0.5, deform_amp=amp)
+    o = O.BrickMesh(p, cells, h=0.5, deform_amp=amp)
+    assert m.n_cells == o.n_cells and m.n_owned == o.n_dofs and m.n_ghost == 0
+    assert m.n_interior_cells == m.n_cells
+    assert np.array_equal(m.l2g, o.l2g)
+    assert np.array_equal(m.constrained, o.constrained)
+    assert np.array_equal(m.global_ids, np.arange(o.n_dofs, dtype=np.uint64))
+    assert np.abs(m.coords - o.coords).max() < 1e-14
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_mesh_partition_consistency(n_ranks):
+    p, cells = 3, (2, 3, 5)
+    o = O.BrickMesh(p, cells, deform_amp=0.04)
+    owned = []
+    total_cells = 0
+    for r in range(n_ranks):
+        m = pkg.BrickMesh(p, cells, deform_amp=0.04, rank=r, n_ranks=n_ranks)
+        total_cells += m.n_cells
+        g = m.global_ids.astype(np.int64)
+        owned.append(g[:m.n_owned])
+        # coordinates / constraints agree with the global mesh
+        assert np.abs(m.coords - o.coords[g]).max() < 1e-14
+        assert set(g[m.constrained.astype(np.int64)]) == set(o.constrained.astype(np.int64)) & set(g)
+        # l2g maps onto the global l2g of some cell
+        cell_sets = {tuple(row) for row in o.l2g.astype(np.int64)}
+        for row in m.l2g.astype(np.int64):
+            assert tuple(g[row]) in cell_sets
+        # interior cells never touch ghosts; the others do
+        touches = (m.l2g >= m.n_owned).any(axis=1)
+        assert not touches[:m.n_interior_cells].any() and touches[m.n_interior_cells:].all()
+        # halo plan shape
+        assert m.n_neighbors == (1 if r in (0, n_ranks - 1) else 2)
+        assert int(m.recv_offsets[-1]) == m.n_ghost
+        assert (m.send_indices < m.n_owned).all()
+    allowned = np.concatenate(owned)
+    assert len(allowned) == o.n_dofs and len(np.unique(allowned)) == o.n_dofs
+    assert total_cells == o.n_cells
+
+
+def test_compute_fails_loudly_without_gpu():
+    """No CPU fallback: without a device bp5_mf_create must return BP5_ERR_NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = pkg.BrickMesh(2, (2, 2, 2))
+    with pytest.raises(pkg.BP5Error) as e:
+        from deal_and_ceed_on_gpu_amd import _lib
+        d = _lib.MFDesc()
+        d.dim, d.degree, d.quadrature = 3, 2, 0
+        d.n_cells, d.n_interior_cells, d.n_owned, d.n_ghost = m.n_cells, m.n_cells, m.n_owned, 0
+        l2g = np.ascontiguousarray(m.l2g)
+        xyz = np.ascontiguousarray(m.coords)
+        cst = np.ascontiguousarray(m.constrained)
+        d.local_to_global_host, d.node_coords_host, d.constrained_host = l2g.ctypes.data, xyz.ctypes.data, cst.ctypes.data
+        d.n_constrained = cst.size
+        h = C.c_void_p()
+        _lib.check(pkg.lib().bp5_mf_create(C.byref(d), C.byref(h)))
+    assert e.value.status == 3
+
+
+def test_product_never_imports_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    root = os.path.join(bp5_pkg.ROOT, "deal-and-ceed-on-gpu_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dp, f)).read()
+                assert "bp5_oracle" not in text and "c_oracle" not in text and "orc_" not in text, os.path.join(dp, f)

@@ -1,0 +1,360 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on the same seeded inputs,
+against the golden fixtures, and -- at full BASELINE sizes -- through size-independent
+properties.  FP64 tolerances are stated per test; the north-star bound is 1e-11 relative l2 on
+the CG solution vector."""
+import os
+
+import numpy as np
+import pytest
+
+import bp5_oracle as O
+import c_oracle as CO
+import bp5_pkg
+from make_golden import CASES_APPLY
+
+pytestmark = pytest.mark.gpu
+pkg = bp5_pkg.load()
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL_OP = 1e-13     # one operator application (rounding + atomic summation order)
+TOL_CG = 1e-11     # CG solution vector at a fixed iteration count (BASELINE north_star)
+
+
+def _t():
+    import torch
+    return torch
+
+
+def dev(x):
+    return _t().from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def kappa_of(km):
+    return O.kappa_step64 if km else O.kappa_none
+
+
+# ------------------------------------------------------------------ geometry (a11, a3)
+@pytest.mark.parametrize("p,quad,cells,amp,km", [(1, 0, (3, 2, 2), 0.05, 0), (2, 1, (2, 3, 2), 0.05, 1), (4, 0, (3, 2, 2), 0.04, 1),
+                                                 (6, 0, (2, 2, 1), 0.05, 0), (8, 1, (2, 1, 1), 0.03, 1)])
+def test_merged_metric(p, quad, cells, amp, km):
+    mesh = pkg.BrickMesh(p, cells, deform_amp=amp)
+    mf = pkg.MatrixFree().reinit(mesh, quad, km)
+    coef = mf.evaluate_coefficients()
+    got = mf.coef_reference_layout(coef).cpu().numpy().reshape(6, mesh.n_cells, -1)
+    pr = O.Problem(p, cells, quad, deform_amp=amp, kappa=kappa_of(km))
+    assert np.abs(got - pr.coef).max() < 1e-13 * np.abs(pr.coef).max()
+    # MatrixFree::Data mirror: inv_jacobian / JxW with deal.II padding
+    d = mf.get_data()
+    n3 = (p + 1) ** 3
+    pad = d.padding_length
+    assert pad >= n3 and (pad & (pad - 1)) == 0
+    import ctypes as C
+    gp = mesh.n_cells * pad
+    K = np.zeros(9 * gp)
+    JxW = np.zeros(gp)
+    pkg.lib().bp5_copy_d2h(K.ctypes.data, d.inv_jacobian, K.nbytes)
+    pkg.lib().bp5_copy_d2h(JxW.ctypes.data, d.JxW, JxW.nbytes)
+    Ko, JxWo, _ = O.jacobians(pr.mesh, pr.N, pr.D, pr.w)
+    K = K.reshape(3, 3, mesh.n_cells, pad)[:, :, :, :n3].transpose(2, 3, 0, 1)
+    assert np.abs(K - Ko).max() < 1e-12
+    assert np.abs(JxW.reshape(mesh.n_cells, pad)[:, :n3] - JxWo).max() < 1e-14
+
+
+# ------------------------------------------------------------------ operator (a1-a10)
+@pytest.mark.parametrize("case", CASES_APPLY)
+def test_vmult_golden(case):
+    p, quad, cells, amp, km = case
+    ref = np.load(os.path.join(G, "vmult_cases.npz"))[f"vmult_p{p}_q{quad}_{cells[0]}x{cells[1]}x{cells[2]}_a{amp}_k{km}"]
+    mesh = pkg.BrickMesh(p, cells, deform_amp=amp)
+    op = pkg.PoissonOperator(mesh, quad, km)
+    s = O.deterministic_src(mesh.n_owned, seed=100 + p)
+    dst = op.initialize_dof_vector()
+    op.vmult(dst, dev(s))
+    assert rel(dst.cpu().numpy(), ref) < TOL_OP
+
+
+@pytest.mark.parametrize("p", range(1, 9))
+@pytest.mark.parametrize("quad", [0, 1])
+def test_cell_loop_all_degrees(p, quad):
+    cells = (3, 3, 2) if p <= 4 else (3, 2, 1)        # cell counts not divisible by the team size
+    pr = O.Problem(p, cells, quad, deform_amp=0.04, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.04)
+    mf = pkg.MatrixFree().reinit(mesh, quad, pkg.COEF_STEP64)
+    coef = mf.evaluate_coefficients()
+    s = O.deterministic_src(mesh.n_owned, seed=3)    # non-zero boundary values too
+    dst = mf.initialize_dof_vector()
+    mf.cell_loop(coef, dev(s), dst)
+    ref = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)
+    assert rel(dst.cpu().numpy(), ref) < TOL_OP
+
+
+@pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1)])
+@pytest.mark.parametrize("quad", [0, 1])
+def test_kernel_variants(p, variant, quad):
+    cells = (7, 3, 1) if p <= 5 else (5, 1, 1)
+    pr = O.Problem(p, cells, quad, deform_amp=0.03)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03)
+    mf = pkg.MatrixFree().reinit(mesh, quad)
+    mf.set_apply_variant(variant)
+    coef = mf.evaluate_coefficients()
+    s = O.deterministic_src(mesh.n_owned, seed=5)
+    dst = mf.initialize_dof_vector()
+    mf.cell_loop(coef, dev(s), dst)
+    ref = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)
+    assert rel(dst.cpu().numpy(), ref) < TOL_OP
+
+
+def test_cell_ranges_and_accumulation():
+    """cell_loop accumulates (do_zero_out = false semantics) and ranges compose."""
+    p, cells = 4, (4, 3, 2)
+    pr = O.Problem(p, cells, 0)
+    mesh = pkg.BrickMesh(p, cells)
+    mf = pkg.MatrixFree().reinit(mesh, 0)
+    coef = mf.evaluate_coefficients()
+    s = O.deterministic_src(mesh.n_owned, seed=11)
+    dst = mf.initialize_dof_vector()
+    src = dev(s)
+    mf.cell_loop(coef, src, dst, 0, 7)
+    mf.cell_loop(coef, src, dst, 7, 7)               # empty range
+    mf.cell_loop(coef, src, dst, 7, mesh.n_cells)
+    ref = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)
+    assert rel(dst.cpu().numpy(), ref) < TOL_OP
+    mf.cell_loop(coef, src, dst)
+    assert rel(dst.cpu().numpy(), 2 * ref) < TOL_OP
+    with pytest.raises(pkg.BP5Error):
+        mf.cell_loop(coef, src, dst, 0, mesh.n_cells + 1)
+    with pytest.raises(pkg.BP5Error):
+        mf.cell_loop(coef, src, src)
+
+
+def test_vmult_dirichlet_and_zero_out_flag():
+    p, cells = 3, (3, 3, 3)
+    pr = O.Problem(p, cells, 0, deform_amp=0.05)
+    op = pkg.PoissonOperator(pkg.BrickMesh(p, cells, deform_amp=0.05), 0)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=3)
+    dst = op.initialize_dof_vector()
+    dst.fill_(123.0)
+    op.vmult(dst, dev(s))
+    ref = pr.vmult(s)
+    got = dst.cpu().numpy()
+    assert rel(got, ref) < TOL_OP
+    c = pr.mesh.constrained.astype(np.int64)
+    assert np.array_equal(got[c], s[c])
+    op.do_zero_out = False                            # bp5/step-64.cu:483: accumulate
+    op.vmult(dst, dev(s))
+    ref2 = 2 * O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)
+    ref2[c] = s[c]
+    assert rel(dst.cpu().numpy(), ref2) < TOL_OP
+
+
+def test_rhs_and_l2_norm():
+    for p, cells, amp in [(2, (8, 8, 8), 0.0), (4, (3, 2, 2), 0.05)]:
+        pr = O.Problem(p, cells, 0, deform_amp=amp)
+        op = pkg.PoissonOperator(pkg.BrickMesh(p, cells, deform_amp=amp), 0)
+        b = op.assemble_rhs().cpu().numpy()
+        assert rel(b, pr.rhs()) < 1e-13
+        u = O.deterministic_src(pr.mesh.n_dofs, pr.mesh.constrained, seed=9)
+        assert abs(op.l2_norm_solution(dev(u)) - O.l2_norm_solution(pr.mesh, u)) < 1e-13 * O.l2_norm_solution(pr.mesh, u)
+
+
+def test_blas1():
+    torch = _t()
+    import ctypes as C
+    mesh = pkg.BrickMesh(1, (2, 2, 2))
+    mf = pkg.MatrixFree().reinit(mesh, 0)
+    L, h = pkg.lib(), mf.handle
+    for n in (1, 2, 255, 100001):
+        rng = np.random.default_rng(n)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        X, Y = dev(x), dev(y)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.bp5_vec_axpy(h, p(Y), 0.5, p(X), n); y = y + 0.5 * x
+        assert np.allclose(Y.cpu().numpy(), y, rtol=1e-15, atol=0)
+        L.bp5_vec_sadd(h, p(Y), -2.0, 3.0, p(X), n); y = -2.0 * y + 3.0 * x
+        assert np.allclose(Y.cpu().numpy(), y, rtol=1e-15, atol=1e-15)
+        r = C.c_double()
+        L.bp5_vec_dot(h, p(X), p(Y), n, C.byref(r))
+        assert abs(r.value - x @ y) < 1e-12 * (np.abs(x) @ np.abs(y))
+        L.bp5_vec_equ(h, p(Y), -1.0, p(X), n)
+        assert np.array_equal(Y.cpu().numpy(), -x)
+        L.bp5_vec_fill(h, p(Y), 2.5, n)
+        assert np.all(Y.cpu().numpy() == 2.5)
+    mf.synchronize()
+
+
+# ------------------------------------------------------------------ CG (a12-a14)
+def test_config1_cg_plain_and_merged():
+    """BASELINE config 1: p=2, 8^3 cells (4913 DoFs), 10 CG iterations."""
+    z = np.load(os.path.join(G, "config1_cg.npz"))
+    mesh = pkg.BrickMesh(2, (8, 8, 8))
+    op = pkg.PoissonOperator(mesh, 0)
+    b = op.assemble_rhs()
+    assert rel(b.cpu().numpy(), z["b"]) < 1e-13
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        x.fill_(7.0)                                      # solve() starts from x0 = 0 regardless
+        ctl = pkg.IterationNumberControl(10, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == 10
+        assert rel(x.cpu().numpy(), z["x"]) < TOL_CG
+        assert abs(ctl.last_value() - z["residuals"][-1]) < 1e-9 * z["residuals"][-1]
+        assert abs(ctl.initial_value() - np.linalg.norm(z["b"])) < 1e-12 * np.linalg.norm(z["b"])
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3, 4, 7, 8])
+def test_merged_cg_epilogue_parity(iters):
+    """The merged solver's deferred x update must reproduce plain CG at every stopping parity
+    (the reference's schedule does not: SURVEY 0.4)."""
+    pr = O.Problem(3, (3, 3, 3), 0, deform_amp=0.04)
+    op = pkg.PoissonOperator(pkg.BrickMesh(3, (3, 3, 3), deform_amp=0.04), 0)
+    b = op.assemble_rhs()
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), iters)
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(iters, 0.0)
+    pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+    assert ctl.last_step() == iters
+    assert rel(x.cpu().numpy(), xr) < TOL_CG
+
+
+def test_p4_variable_coefficient_deformed_cg_golden():
+    z = np.load(os.path.join(G, "p4_kappa_deformed_cg.npz"))
+    op = pkg.PoissonOperator(pkg.BrickMesh(4, (4, 3, 3), deform_amp=0.04), 0, pkg.COEF_STEP64)
+    b = op.assemble_rhs()
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(20, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == 20 and rel(x.cpu().numpy(), z["x"]) < TOL_CG
+
+
+@pytest.mark.parametrize("check_every", [0, 1, 5])
+def test_cg_tolerance_stop_and_frozen_iterate(check_every):
+    """IterationNumberControl(max, tol): stops at the first iteration with res <= tol; the
+    iterate is frozen on device from then on whatever the host polling period."""
+    pr = O.Problem(2, (4, 4, 4), 0)
+    op = pkg.PoissonOperator(pkg.BrickMesh(2, (4, 4, 4)), 0)
+    b = op.assemble_rhs()
+    bn = np.linalg.norm(pr.rhs())
+    xr, kr, resr = O.cg_plain(pr.vmult, pr.rhs(), 500, tol=1e-6 * bn)
+    assert 3 < kr < 100
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(kr + 13, 1e-6 * bn)
+        solver(ctl, check_every=check_every).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == kr
+        assert rel(x.cpu().numpy(), xr) < 1e-10
+        assert ctl.last_value() <= 1e-6 * bn
+
+
+def test_cg_with_diagonal_preconditioner_vector():
+    """A non-trivial DiagonalMatrix goes through the same kernels (bp5/solver.h:68,100,131,170)."""
+    pr = O.Problem(2, (3, 3, 3), 0, deform_amp=0.05)
+    op = pkg.PoissonOperator(pkg.BrickMesh(2, (3, 3, 3), deform_amp=0.05), 0)
+    rng = np.random.default_rng(4)
+    diag = rng.uniform(0.5, 2.0, pr.mesh.n_dofs)
+    b = op.assemble_rhs()
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 12, diag=diag)
+    xm, _, _ = O.cg_merged(pr.vmult, pr.rhs(), 12, diag=diag)
+    assert rel(xm, xr) < 1e-12
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(12, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix(dev(diag)))
+        assert rel(x.cpu().numpy(), xr) < TOL_CG
+
+
+def test_medium_size_against_c_oracle():
+    """p=4, 12^3 cells (117 649 DoFs), variable coefficient, deformed: 25 CG iterations vs the
+    C restatement, plus profile counters."""
+    p, cells = 4, (12, 12, 12)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.04)
+    cp = CO.CProblem(p, 0, mesh.l2g, mesh.coords, mesh.constrained, 1)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    b = op.assemble_rhs()
+    bref = cp.rhs()
+    assert rel(b.cpu().numpy(), bref) < 1e-13
+    xr, kr, resr = cp.cg_plain(bref, 25)
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(25, 0.0)
+    pkg.SolverCG(ctl, profile=True).solve(op, x, b, pkg.DiagonalMatrix())
+    assert ctl.last_step() == 25 and ctl.apply_launches == 25 and ctl.apply_ms_avg > 0
+    assert rel(x.cpu().numpy(), xr) < TOL_CG
+    assert abs(ctl.last_value() - resr) < 1e-9 * resr
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("p,cells,quad,amp,km", [(4, (54, 54, 54), 0, 0.0, 1),      # BASELINE config 2
+                                                 (6, (30, 30, 30), 0, 0.05, 0)])     # config 5 shape, reduced
+def test_full_size_properties(p, cells, quad, amp, km):
+    """Size-independent properties at BASELINE scale: constants in the null space of the cell
+    loop, symmetry, linearity; CG residual consistency."""
+    torch = _t()
+    import ctypes as C
+    mesh = pkg.BrickMesh(p, cells, deform_amp=amp)
+    op = pkg.PoissonOperator(mesh, quad, km)
+    mf = op.mf_data
+    n = mesh.n_owned
+    L, h = pkg.lib(), mf.handle
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+
+    def dot(a, b):
+        r = C.c_double()
+        L.bp5_vec_dot(h, ptr(a), ptr(b), n, C.byref(r))
+        return r.value
+
+    one = torch.ones(n, dtype=torch.float64, device="cuda:0")
+    y = mf.initialize_dof_vector()
+    mf.cell_loop(op.coef, one, y)
+    scale = float(torch.abs(op.coef[: mesh.n_cells * (p + 1) ** 3]).max())
+    assert float(torch.abs(y).max()) < 1e-11 * scale * (p + 1) ** 3
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    u = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
+    v = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
+    Au, Av, Auv = (mf.initialize_dof_vector() for _ in range(3))
+    op.vmult(Au, u)
+    op.vmult(Av, v)
+    vAu, uAv = dot(v, Au), dot(u, Av)
+    # Dirichlet rows are identity: symmetric as well
+    assert abs(vAu - uAv) < 1e-11 * max(abs(vAu), dot(u, Au))
+    assert dot(u, Au) > 0
+    w = 2.0 * u - 3.0 * v
+    op.vmult(Auv, w)
+    lin = 2.0 * Au - 3.0 * Av
+    assert float(torch.linalg.norm(Auv - lin)) < 1e-12 * float(torch.linalg.norm(lin))
+    # CG: recomputed residual ||A x - b|| equals the recurrence residual
+    b = op.assemble_rhs()
+    x = mf.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(15, 0.0)
+    pkg.SolverCG(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+    op.vmult(Au, x)
+    true_res = float(torch.linalg.norm(Au - b))
+    assert abs(true_res - ctl.last_value()) < 1e-9 * ctl.initial_value()
+    x2 = mf.initialize_dof_vector()
+    ctl2 = pkg.IterationNumberControl(15, 0.0)
+    pkg.SolverCGFullMerge(ctl2).solve(op, x2, b, pkg.DiagonalMatrix())
+    assert float(torch.linalg.norm(x2 - x)) < TOL_CG * float(torch.linalg.norm(x))
+
+
+def test_single_rank_communicator_and_distributed_entry_points():
+    """RCCL bootstrap with one rank: allreduce / halo calls are no-ops but exercise the symbols."""
+    comm = pkg.Communicator(0, 1)
+    pr = O.Problem(2, (3, 3, 3), 0)
+    op = pkg.PoissonOperator(pkg.BrickMesh(2, (3, 3, 3)), 0, comm=comm)
+    b = op.assemble_rhs()
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(8, 0.0)
+    pkg.SolverCG(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 8)
+    assert rel(x.cpu().numpy(), xr) < TOL_CG
+    import ctypes as C
+    L = pkg.lib()
+    s = dev(O.deterministic_src(pr.mesh.n_dofs, seed=2))
+    d = op.initialize_dof_vector()
+    assert L.bp5_apply_distributed(op.mf_data.handle, C.c_void_p(op.coef.data_ptr()), C.c_void_p(s.data_ptr()),
+                                   C.c_void_p(d.data_ptr()), 1) == 0
+    assert rel(d.cpu().numpy(), pr.vmult(s.cpu().numpy())) < TOL_OP
+    op.mf_data.synchronize()
+    comm.close()
