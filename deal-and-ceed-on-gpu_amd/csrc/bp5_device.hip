@@ -134,8 +134,7 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     if (d->local_to_global_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "local_to_global entry out of range"); }
   for (uint32_t s = 0; s < d->n_constrained; ++s)
     if (d->constrained_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "constrained index out of range"); }
-  if (d->stream) mf->stream = (hipStream_t)d->stream;
-  else { HIP_TRY(hipStreamCreateWithFlags(&mf->stream, hipStreamNonBlocking)); mf->own_stream = true; }
+  mf->stream = (hipStream_t)d->stream; // NULL == the HIP default stream (ordered with the host's other default-stream work)
   BP5_TRY(upload(&mf->d_l2g, d->local_to_global_host, nl));
   BP5_TRY(upload(&mf->d_coords, d->node_coords_host, nloc * 3));
   BP5_TRY(upload(&mf->d_constrained, d->constrained_host, d->n_constrained));

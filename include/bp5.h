@@ -124,7 +124,7 @@ typedef struct {
   const int *neighbor_rank_host;
   const uint32_t *send_offsets_host, *send_indices_host, *recv_offsets_host;
   int device;              /* HIP device ordinal                                                */
-  void *stream;            /* hipStream_t or NULL (= a private non-blocking stream)             */
+  void *stream;            /* hipStream_t; NULL = the HIP default (null) stream                 */
 } bp5_mf_desc;
 
 /* == MatrixFree::reinit(mapping, dof_handler, constraints, quad, additional_data),

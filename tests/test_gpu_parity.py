@@ -221,13 +221,14 @@ def test_merged_cg_epilogue_parity(iters):
 
 def test_p4_variable_coefficient_deformed_cg_golden():
     z = np.load(os.path.join(G, "p4_kappa_deformed_cg.npz"))
-    op = pkg.PoissonOperator(pkg.BrickMesh(4, (4, 3, 3), deform_amp=0.04), 0, pkg.COEF_STEP64)
+    op = pkg.PoissonOperator(pkg.BrickMesh(4, (4, 3, 3), h=0.25, deform_amp=0.04), 0, pkg.COEF_STEP64)
     b = op.assemble_rhs()
+    assert rel(b.cpu().numpy(), z["b"]) < 1e-13
     for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
         x = op.initialize_dof_vector()
-        ctl = pkg.IterationNumberControl(20, 0.0)
+        ctl = pkg.IterationNumberControl(12, 0.0)
         solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
-        assert ctl.last_step() == 20 and rel(x.cpu().numpy(), z["x"]) < TOL_CG
+        assert ctl.last_step() == 12 and rel(x.cpu().numpy(), z["x"]) < TOL_CG
 
 
 @pytest.mark.parametrize("check_every", [0, 1, 5])
@@ -267,20 +268,21 @@ def test_cg_with_diagonal_preconditioner_vector():
 
 
 def test_medium_size_against_c_oracle():
-    """p=4, 12^3 cells (117 649 DoFs), variable coefficient, deformed: 25 CG iterations vs the
-    C restatement, plus profile counters."""
+    """p=4, 12^3 cells (117 649 DoFs) on the unit cube, variable coefficient, deformed: 20 CG
+    iterations vs the C restatement (rounding-perturbation drift of this case: 2e-15), plus
+    profile counters."""
     p, cells = 4, (12, 12, 12)
-    mesh = pkg.BrickMesh(p, cells, deform_amp=0.04)
+    mesh = pkg.BrickMesh(p, cells, h=1.0 / 12, deform_amp=0.04)
     cp = CO.CProblem(p, 0, mesh.l2g, mesh.coords, mesh.constrained, 1)
     op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
     b = op.assemble_rhs()
     bref = cp.rhs()
     assert rel(b.cpu().numpy(), bref) < 1e-13
-    xr, kr, resr = cp.cg_plain(bref, 25)
+    xr, kr, resr = cp.cg_plain(bref, 20)
     x = op.initialize_dof_vector()
-    ctl = pkg.IterationNumberControl(25, 0.0)
+    ctl = pkg.IterationNumberControl(20, 0.0)
     pkg.SolverCG(ctl, profile=True).solve(op, x, b, pkg.DiagonalMatrix())
-    assert ctl.last_step() == 25 and ctl.apply_launches == 25 and ctl.apply_ms_avg > 0
+    assert ctl.last_step() == 20 and ctl.apply_launches == 20 and ctl.apply_ms_avg > 0
     assert rel(x.cpu().numpy(), xr) < TOL_CG
     assert abs(ctl.last_value() - resr) < 1e-9 * resr
 
@@ -293,7 +295,7 @@ def test_full_size_properties(p, cells, quad, amp, km):
     loop, symmetry, linearity; CG residual consistency."""
     torch = _t()
     import ctypes as C
-    mesh = pkg.BrickMesh(p, cells, deform_amp=amp)
+    mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=amp)
     op = pkg.PoissonOperator(mesh, quad, km)
     mf = op.mf_data
     n = mesh.n_owned
@@ -313,11 +315,12 @@ def test_full_size_properties(p, cells, quad, amp, km):
     g = torch.Generator(device="cuda:0").manual_seed(1)
     u = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
     v = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
+    mf.set_constrained_values(0.0, u)                  # A_eff = P A P + (I - P) is symmetric on
+    mf.set_constrained_values(0.0, v)                  # vectors that vanish on Dirichlet DoFs
     Au, Av, Auv = (mf.initialize_dof_vector() for _ in range(3))
     op.vmult(Au, u)
     op.vmult(Av, v)
     vAu, uAv = dot(v, Au), dot(u, Av)
-    # Dirichlet rows are identity: symmetric as well
     assert abs(vAu - uAv) < 1e-11 * max(abs(vAu), dot(u, Au))
     assert dot(u, Au) > 0
     w = 2.0 * u - 3.0 * v
