@@ -44,7 +44,7 @@ HEADER_SYMBOLS = _header_symbols()
 
 class MeshDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("cells", C.c_uint32 * 3), ("h", C.c_double), ("deform_amp", C.c_double),
-                ("rank", C.c_int), ("n_ranks", C.c_int)]
+                ("rank", C.c_int), ("n_ranks", C.c_int), ("cell_block", C.c_uint32 * 3), ("dof_numbering", C.c_int)]
 
 
 class MeshView(C.Structure):
@@ -54,7 +54,8 @@ class MeshView(C.Structure):
                 ("global_ids_host", C.POINTER(C.c_uint64)), ("constrained_host", C.POINTER(C.c_uint32)),
                 ("n_constrained", C.c_uint32), ("n_neighbors", C.c_int), ("neighbor_rank_host", C.POINTER(C.c_int)),
                 ("send_offsets_host", C.POINTER(C.c_uint32)), ("send_indices_host", C.POINTER(C.c_uint32)),
-                ("recv_offsets_host", C.POINTER(C.c_uint32))]
+                ("recv_offsets_host", C.POINTER(C.c_uint32)), ("n_cell_blocks", C.c_uint32),
+                ("cell_block_offsets_host", C.POINTER(C.c_uint32))]
 
 
 class MFDesc(C.Structure):
@@ -63,7 +64,8 @@ class MFDesc(C.Structure):
                 ("local_to_global_host", C.c_void_p), ("node_coords_host", C.c_void_p), ("constrained_host", C.c_void_p),
                 ("n_constrained", C.c_uint32), ("n_neighbors", C.c_int), ("neighbor_rank_host", C.c_void_p),
                 ("send_offsets_host", C.c_void_p), ("send_indices_host", C.c_void_p), ("recv_offsets_host", C.c_void_p),
-                ("device", C.c_int), ("stream", C.c_void_p)]
+                ("device", C.c_int), ("stream", C.c_void_p), ("n_cell_blocks", C.c_uint32),
+                ("cell_block_offsets_host", C.c_void_p)]
 
 
 class MFData(C.Structure):

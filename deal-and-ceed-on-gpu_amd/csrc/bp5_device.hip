@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <vector>
 
 using namespace bp5;
@@ -44,7 +45,8 @@ struct bp5_event {
 struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
-  int apply_variant = 0;
+  int apply_variant = 0, n_cus = 0;
+  bool force_atomic_scatter = false;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   Tables tab, tab_gauss;
@@ -67,6 +69,19 @@ struct bp5_mf {
   double *h_sc = nullptr; // pinned
   int *h_st = nullptr;    // pinned
   std::vector<hipEvent_t> ev_pool;
+  // team plans of the team-assembled kernel, keyed by cells per team
+  std::vector<uint32_t> h_l2g;
+  struct DevPlan {
+    uint32_t *off = nullptr, *dofs = nullptr, *sh_dof = nullptr, *sh_off = nullptr, *sh_slot = nullptr;
+    uint16_t *pos = nullptr;
+    uint8_t *cell_round = nullptr, *team_rounds = nullptr;
+    double *partial = nullptr;
+    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr;
+    uint32_t n_shared = 0, n_groups = 0, max_list = 0;
+    bool covers_all = false;
+  };
+  std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
+  std::map<int, DevPlan> plans;
   size_t n_local() const { return (size_t)n_owned + n_ghost; }
 };
 
@@ -136,6 +151,14 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     if (d->constrained_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "constrained index out of range"); }
   mf->stream = (hipStream_t)d->stream; // NULL == the HIP default stream (ordered with the host's other default-stream work)
   BP5_TRY(upload(&mf->d_l2g, d->local_to_global_host, nl));
+  mf->h_l2g.assign(d->local_to_global_host, d->local_to_global_host + nl);
+  if (d->n_cell_blocks && d->cell_block_offsets_host) {
+    const uint32_t *o = d->cell_block_offsets_host;
+    bool ok = o[0] == 0 && o[d->n_cell_blocks] == d->n_cells;
+    for (uint32_t b = 0; ok && b < d->n_cell_blocks; ++b) ok = o[b] < o[b + 1];
+    if (!ok) { delete mf; return fail(BP5_ERR_INVALID, "cell_block_offsets must ascend from 0 to n_cells"); }
+    mf->h_block_off.assign(o, o + d->n_cell_blocks + 1);
+  }
   BP5_TRY(upload(&mf->d_coords, d->node_coords_host, nloc * 3));
   BP5_TRY(upload(&mf->d_constrained, d->constrained_host, d->n_constrained));
   std::vector<double> tv;
@@ -180,6 +203,11 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
   for (hipEvent_t e : mf->ev_pool) hipEventDestroy(e);
+  for (auto &kv : mf->plans) {
+    auto &q = kv.second;
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off};
+    for (void *x : pp) if (x) hipFree(x);
+  }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
   delete mf;
   return BP5_OK;
@@ -299,7 +327,7 @@ extern "C" int bp5_mf_get_data(bp5_mf *mf, int color, bp5_mf_data *out)
 }
 
 // ------------------------------------------------------------------------------------ operator
-template <int P, bool COLL, int TW, int LPC, int TPB, bool PF>
+template <int P, bool COLL, int TW, int LPC, int TPB, bool PF, int ABL = 0>
 static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
 {
   constexpr int n = P + 1;
@@ -316,27 +344,183 @@ static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   memcpy(sh.N, mf->tab.N, sizeof(sh.N));
   memcpy(sh.D, mf->tab.D, sizeof(sh.D));
   const size_t lds = (size_t)TPB * CPT * L::CS * sizeof(double);
-  hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
+  hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF, ABL>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
                      sh);
   KERNEL_CHECK();
   return BP5_OK;
 }
 
+// key > 0: uniform teams of `key` cells (team kernel); key < 0: cell blocks walked in passes of
+// -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
+static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block = 64)
+{
+  auto it = mf->plans.find(key);
+  if (it == mf->plans.end()) {
+    TeamPlanHost h;
+    if (key > 0) BP5_TRY(build_team_plan(mf->h_l2g.data(), mf->n_cells, mf->n3, mf->n_local(), key, h));
+    else if (!mf->h_block_off.empty())
+      BP5_TRY(build_team_plan(mf->h_l2g.data(), mf->n_cells, mf->n3, mf->n_local(), 0, h, mf->h_block_off.data(),
+                              (uint32_t)mf->h_block_off.size() - 1, -key));
+    else BP5_TRY(build_team_plan(mf->h_l2g.data(), mf->n_cells, mf->n3, mf->n_local(), default_block, h, nullptr, 0, -key));
+    bp5_mf::DevPlan dp;
+    BP5_TRY(upload(&dp.off, h.off.data(), h.off.size()));
+    BP5_TRY(upload(&dp.dofs, h.dofs.data(), h.dofs.size()));
+    BP5_TRY(upload(&dp.pos, h.pos.data(), h.pos.size()));
+    BP5_TRY(upload(&dp.cell_round, h.cell_round.data(), h.cell_round.size()));
+    BP5_TRY(upload(&dp.team_rounds, h.team_rounds.data(), h.team_rounds.size()));
+    BP5_TRY(upload(&dp.sh_dof, h.sh_dof.data(), h.sh_dof.size()));
+    BP5_TRY(upload(&dp.sh_off, h.sh_off.data(), h.sh_off.size()));
+    BP5_TRY(upload(&dp.sh_slot, h.sh_slot.data(), h.sh_slot.size()));
+    HIP_TRY(hipMalloc((void **)&dp.partial, std::max<size_t>(h.dofs.size(), 1) * sizeof(double)));
+    HIP_TRY(hipMemset(dp.partial, 0, std::max<size_t>(h.dofs.size(), 1) * sizeof(double)));
+    BP5_TRY(upload(&dp.cell_off, h.group_cell_off.data(), h.group_cell_off.size()));
+    if (key < 0) {
+      BP5_TRY(upload(&dp.pass_cell, h.pass_cell.data(), h.pass_cell.size()));
+      BP5_TRY(upload(&dp.pass_off, h.pass_off.data(), h.pass_off.size()));
+    }
+    dp.n_shared = (uint32_t)h.sh_dof.size();
+    dp.covers_all = h.covers_all;
+    dp.n_groups = (uint32_t)h.group_cell_off.size() - 1;
+    for (uint32_t g = 0; g < dp.n_groups; ++g) dp.max_list = std::max(dp.max_list, h.off[g + 1] - h.off[g]);
+    it = mf->plans.emplace(key, dp).first;
+  }
+  *dpo = &it->second;
+  return BP5_OK;
+}
+static int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
+{
+  bp5_mf::DevPlan *q = nullptr;
+  BP5_TRY(get_plan_raw(mf, cpt, &q));
+  tp.off = q->off; tp.dofs = q->dofs; tp.pos = q->pos; tp.cell_round = q->cell_round; tp.team_rounds = q->team_rounds; tp.partial = q->partial;
+  if (dpo) *dpo = q;
+  return BP5_OK;
+}
+
+static int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
+{
+  if (!dp->n_shared) return BP5_OK;
+  const dim3 cg((dp->n_shared + 255) / 256);
+  if (set) hipLaunchKernelGGL(combine_kernel<false>, cg, dim3(256), 0, mf->stream, dp->sh_dof, dp->sh_off, dp->sh_slot, dp->partial, dst, dp->n_shared);
+  else hipLaunchKernelGGL(combine_kernel<true>, cg, dim3(256), 0, mf->stream, dp->sh_dof, dp->sh_off, dp->sh_slot, dp->partial, dst, dp->n_shared);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+
+constexpr size_t BLOCK_LDS_BUDGET = 80 * 1024; // two workgroups per CU (160 KiB LDS)
+
+// block-assembled kernel; falls back to the team kernel path when the range is partial
+template <int P, bool COLL, int LPC, int ABL = 0>
+static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, double *dst, bool overwrite)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 256 / LPC;
+  using L = LdsLayout<n, LPC>;
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan_raw(mf, -CPT, &dp));
+  const size_t lds = ((size_t)CPT * L::CS + dp->max_list) * sizeof(double);
+  if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
+  BlockPlan bp;
+  bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos;
+  bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
+  // persistent grid: two workgroups per CU (LDS budget), a multiple of 8 for the XCD mapping
+  if (!mf->n_cus) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
+    mf->n_cus = prop.multiProcessorCount;
+  }
+  const int wg_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
+  n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (dp->n_groups + 7) / 8 * 8) / 8 * 8);
+  bp.n_wg = n_wg;
+  ApplyArgs a;
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const bool set = overwrite && dp->covers_all;
+  if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  const dim3 grid(n_wg), block(256);
+  if (set) {
+    auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET, ABL>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+  } else {
+    auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD, ABL>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+  }
+  KERNEL_CHECK();
+  if (ABL) return BP5_OK;
+  return launch_combine(mf, dp, dst, set);
+}
+
+// overwrite == true: dst need not be zeroed by the caller, the launch defines every entry
+template <int P, bool COLL, int TW, int LPC, bool PF>
+static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 64 * TW / LPC;
+  using L = LdsLayout<n, LPC>;
+  TeamPlan tp;
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan(mf, CPT, tp, &dp));
+  ApplyArgs a;
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = c0; a.cell_end = c1;
+  a.n_teams = (c1 + CPT - 1) / CPT - c0 / CPT;
+  a.teams_per_xcd = (a.n_teams + 7) / 8;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const size_t lds = (size_t)CPT * L::CS * sizeof(double);
+  const dim3 grid(a.teams_per_xcd * 8), block(64 * TW);
+  const bool whole = (c0 == 0 && c1 == mf->n_cells);
+  if (!whole || mf->force_atomic_scatter) {
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_ATOMIC>), grid, block, lds, mf->stream, a, tp, sh);
+  } else {
+    const bool set = overwrite && dp->covers_all;
+    if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    if (set) hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_SET>), grid, block, lds, mf->stream, a, tp, sh);
+    else hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_ADD>), grid, block, lds, mf->stream, a, tp, sh);
+    KERNEL_CHECK();
+    return launch_combine(mf, dp, dst, set);
+  }
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+#define TEAM_CASE(P, V, TW, LPC, PF)                                                                               \
+  case (P)*100 + (V):                                                                                              \
+    return coll ? launch_team_t<P, true, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)                       \
+                : launch_team_t<P, false, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)
+
 // variant table: (degree, variant) -> (TW, LPC, TPB, PF); variant 0 = default for the degree
 #define APPLY_CASE(P, V, TW, LPC, TPB, PF)                                                                         \
   case (P)*100 + (V):                                                                                              \
+    if (overwrite && hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream) != hipSuccess)             \
+      return fail(BP5_ERR_HIP, "hipMemsetAsync");                                                                  \
     return coll ? launch_apply_t<P, true, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)                            \
                 : launch_apply_t<P, false, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)
 
-static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
+// overwrite: the launch must leave dst = A src (no prior zeroing by the caller); otherwise dst += A src
+static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite = false)
 {
-  if (c1 <= c0) return BP5_OK;
+  if (c1 <= c0) {
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    return BP5_OK;
+  }
   const bool coll = mf->quadrature == BP5_QUAD_GLL;
-  switch (mf->degree * 100 + mf->apply_variant) {
+  // variants >= 100: the team kernel of (variant - 100) with the global-atomic scatter (A/B tests)
+  mf->force_atomic_scatter = mf->apply_variant >= 100;
+  switch (mf->degree * 100 + mf->apply_variant % 100) {
     APPLY_CASE(1, 0, 1, 4, 4, true);
     APPLY_CASE(2, 0, 1, 9, 4, true);
     APPLY_CASE(3, 0, 1, 16, 4, true);
-    APPLY_CASE(4, 0, 1, 25, 4, true);
+    APPLY_CASE(4, 0, 4, 25, 1, true);
+    APPLY_CASE(4, 6, 1, 25, 4, true);
     APPLY_CASE(4, 1, 1, 32, 4, true);
     APPLY_CASE(4, 2, 2, 25, 1, true);
     APPLY_CASE(4, 3, 4, 25, 1, true);
@@ -349,6 +533,52 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     APPLY_CASE(7, 0, 1, 64, 4, false);
     APPLY_CASE(8, 0, 4, 81, 1, false);
     APPLY_CASE(8, 1, 2, 81, 1, false);
+    // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
+#define ABL_CASE(M) case 400 + 20 + (M): return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
+    ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(5); ABL_CASE(7); ABL_CASE(8); ABL_CASE(9); ABL_CASE(15); ABL_CASE(14); ABL_CASE(13); ABL_CASE(11);
+    // block-assembled kernel (compact cell blocks, LDS accumulator, no atomics), variants 50+;
+    // a partial cell range cannot use the owner scatter and takes the atomic team kernel instead
+#define BLOCK_CASE(P, V, LPC, TW_FALLBACK, PF)                                                                     \
+  case (P)*100 + (V):                                                                                              \
+    if (c0 != 0 || c1 != mf->n_cells)                                                                              \
+      return coll ? launch_team_t<P, true, TW_FALLBACK, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)            \
+                  : launch_team_t<P, false, TW_FALLBACK, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite);          \
+    return coll ? launch_block_t<P, true, LPC>(mf, coef, src, dst, overwrite) : launch_block_t<P, false, LPC>(mf, coef, src, dst, overwrite)
+    BLOCK_CASE(1, 50, 4, 4, true);
+    BLOCK_CASE(2, 50, 9, 4, true);
+    BLOCK_CASE(3, 50, 16, 4, true);
+    BLOCK_CASE(4, 50, 25, 4, true);
+    BLOCK_CASE(4, 51, 32, 4, true);
+    BLOCK_CASE(5, 50, 36, 4, true);
+    BLOCK_CASE(6, 50, 49, 4, false);
+    BLOCK_CASE(7, 50, 64, 4, false);
+    BLOCK_CASE(8, 50, 81, 4, false);
+#define BABL_CASE(M) case 400 + 60 + (M): return launch_block_t<4, false, 25, M>(mf, coef, src, dst, true)
+    BABL_CASE(16); BABL_CASE(1); BABL_CASE(2); BABL_CASE(3); BABL_CASE(4); BABL_CASE(5); BABL_CASE(7); BABL_CASE(8); BABL_CASE(9); BABL_CASE(15);
+    // timing-only ablations of the team kernel (SET mode): 40 + mask (1: no scatter stage, 4: no gather stage)
+#define TABL_CASE(M)                                                                                               \
+  case 400 + 40 + (M): {                                                                                           \
+    TeamPlan tp; bp5_mf::DevPlan *dp = nullptr;                                                                    \
+    BP5_TRY(get_plan(mf, 10, tp, &dp));                                                                            \
+    ApplyArgs a; a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst; a.plane_stride = (uint64_t)mf->n_cells * mf->n3; \
+    a.cell_begin = c0; a.cell_end = c1; a.n_teams = (c1 + 9) / 10 - c0 / 10; a.teams_per_xcd = (a.n_teams + 7) / 8;  \
+    ShapeArg<5> sh; memcpy(sh.N, mf->tab.N, sizeof(sh.N)); memcpy(sh.D, mf->tab.D, sizeof(sh.D));                  \
+    hipLaunchKernelGGL((apply_team_kernel<4, false, 4, 25, true, SC_OWNER_SET, M>), dim3(a.teams_per_xcd * 8), dim3(256), \
+                       (10 * LdsLayout<5, 25>::CS * sizeof(double)), mf->stream, a, tp, sh);                          \
+    KERNEL_CHECK(); return BP5_OK; }
+    TABL_CASE(0); TABL_CASE(1); TABL_CASE(4); TABL_CASE(5);
+    // team-assembled kernel (LDS-staged gather + scatter), variants 10+
+    TEAM_CASE(1, 10, 4, 4, true);
+    TEAM_CASE(2, 10, 4, 9, true);
+    TEAM_CASE(3, 10, 4, 16, true);
+    TEAM_CASE(4, 10, 4, 25, true);
+    TEAM_CASE(4, 11, 8, 25, true);
+    TEAM_CASE(4, 12, 4, 25, false);
+    TEAM_CASE(4, 13, 2, 25, true);
+    TEAM_CASE(5, 10, 4, 36, true);
+    TEAM_CASE(6, 10, 4, 49, false);
+    TEAM_CASE(7, 10, 4, 64, false);
+    TEAM_CASE(8, 10, 4, 81, false);
   }
   return fail(BP5_ERR_INVALID, "unknown (degree, apply variant)");
 }
@@ -384,8 +614,7 @@ extern "C" int bp5_apply(bp5_mf *mf, const double *coef, const double *src, doub
   if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
   if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
   HIP_TRY(hipSetDevice(mf->device));
-  if (zero_dst) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells));
+  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero_dst != 0));
   return bp5_copy_constrained(mf, src, dst);
 }
 
@@ -582,11 +811,10 @@ extern "C" int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src
   if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
   if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
   HIP_TRY(hipSetDevice(mf->device));
-  if (zero_dst) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   // stream order: ghost gather, all cells, scatter-add.  (Interior cells [0,n_interior) do not
   // read ghosts; the overlapped 3-phase schedule of SURVEY 3.2 is a later optimisation.)
   BP5_TRY(bp5_halo_gather(mf, src));
-  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells));
+  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero_dst != 0));
   BP5_TRY(bp5_halo_scatter_add(mf, dst));
   BP5_TRY(bp5_halo_zero_ghosts(mf, src));
   return bp5_copy_constrained(mf, src, dst);
@@ -665,10 +893,9 @@ struct ApplyProfile {
 static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof)
 {
   const bool dist = mf->comm && mf->comm->n_ranks > 1;
-  if (zero) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   if (dist) BP5_TRY(bp5_halo_gather(mf, src));
   BP5_TRY(prof.begin());
-  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells));
+  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero));
   BP5_TRY(prof.end());
   if (dist) { BP5_TRY(bp5_halo_scatter_add(mf, dst)); BP5_TRY(bp5_halo_zero_ghosts(mf, src)); }
   return bp5_copy_constrained(mf, src, dst);
@@ -750,7 +977,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
       else if (it % 2 == 0) hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
       else hipLaunchKernelGGL(cgm_update_kernel<2>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
       KERNEL_CHECK();
-      BP5_TRY(solver_vmult(mf, coef, d, h, false, prof)); // v was zeroed by the update (do_zero_out = false, bp5/step-64.cu:483)
+      BP5_TRY(solver_vmult(mf, coef, d, h, true, prof)); // overwrite mode: v needs no zeroing (the reference zeroes it in update_a*)
       hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid1), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
       hipLaunchKernelGGL(finalize_kernel<7>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_R0, mf->d_st);
       KERNEL_CHECK();

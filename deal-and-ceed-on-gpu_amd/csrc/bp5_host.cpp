@@ -122,6 +122,142 @@ int shape_tables(int degree, int quadrature, Tables &t)
     }
   return BP5_OK;
 }
+
+// ---------------------------------------------------------------------------------- team plan
+int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_local, int cpt, TeamPlanHost &out,
+                    const uint32_t *blk_off, uint32_t n_blocks, int cells_per_pass)
+{
+  // groups: either uniform teams of `cpt` consecutive cells, or the explicit blocks blk_off[]
+  std::vector<uint32_t> goff;
+  if (blk_off) goff.assign(blk_off, blk_off + n_blocks + 1);
+  else for (size_t c0 = 0;; c0 += cpt) { goff.push_back((uint32_t)std::min<size_t>(c0, n_cells)); if (c0 >= n_cells) break; }
+  out.group_cell_off = goff;
+  if (n_local >= (1ull << 31)) return fail(BP5_ERR_UNSUPPORTED, "team plan needs fewer than 2^31 local DoFs");
+  const size_t n_teams = goff.size() - 1;
+
+  out.off.assign(n_teams + 1, 0);
+  out.pos.assign((size_t)n_cells * n3, 0);
+  std::vector<uint32_t> count(n_teams, 0);
+  // pass 1: distinct count per team, positions
+  std::vector<std::vector<uint32_t>> lists(n_teams);
+#pragma omp parallel
+  {
+    std::vector<uint32_t> tmp;
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t t = 0; t < (int64_t)n_teams; ++t) {
+      const size_t c0 = goff[t], c1 = goff[t + 1];
+      tmp.assign(l2g + c0 * n3, l2g + c1 * n3);
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      for (size_t s = c0 * n3; s < c1 * n3; ++s)
+        out.pos[s] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), l2g[s]) - tmp.begin());
+      lists[t] = tmp;
+    }
+  }
+  for (size_t t = 0; t < n_teams; ++t) {
+    if (lists[t].size() > 65536) return fail(BP5_ERR_UNSUPPORTED, "cell group touches more than 65536 DoFs (16-bit positions)");
+    out.off[t + 1] = out.off[t] + (uint32_t)lists[t].size();
+  }
+  out.dofs.resize(out.off[n_teams]);
+  std::vector<uint8_t> mult(n_local, 0);
+  for (size_t t = 0; t < n_teams; ++t)
+    for (uint32_t g : lists[t]) if (mult[g] < 2) ++mult[g];
+  out.covers_all = true;
+  for (size_t g = 0; g < n_local; ++g) if (!mult[g]) { out.covers_all = false; break; }
+#pragma omp parallel for schedule(static)
+  for (int64_t t = 0; t < (int64_t)n_teams; ++t) {
+    uint32_t *d = out.dofs.data() + out.off[t];
+    for (size_t i = 0; i < lists[t].size(); ++i) d[i] = lists[t][i] | (mult[lists[t][i]] == 1 ? 0x80000000u : 0u);
+  }
+  // accumulation order.  Team kernel (cells_per_pass == 0): one pass per group, greedy colouring of
+  // its cells into rounds.  Block kernel: the cells of a group are packed into passes of
+  // cells_per_pass slots such that cells of one pass share no DoF whenever possible (for a brick
+  // of hexes these are the 2x2x2 parity classes); only if a pass cannot be filled that way are
+  // conflicting cells admitted, in a later round of that pass.
+  out.cell_round.assign(n_cells, 0);
+  out.team_rounds.assign(n_teams, 1);
+  if (cells_per_pass > 0) out.pass_off.assign(n_teams + 1, 0);
+  std::vector<std::vector<uint32_t>> group_passes(cells_per_pass > 0 ? n_teams : 0);
+#pragma omp parallel
+  {
+    std::vector<uint64_t> pos_mask; // per list entry: bitmask of passes (or rounds) already using it
+    std::vector<int> fill;
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t t = 0; t < (int64_t)n_teams; ++t) {
+      const size_t c0 = goff[t], c1 = goff[t + 1];
+      pos_mask.assign(lists[t].size(), 0ull);
+      if (cells_per_pass <= 0) {
+        uint8_t nr = 1;
+        for (size_t c = c0; c < c1; ++c) {
+          uint64_t used = 0;
+          for (int i = 0; i < n3; ++i) used |= pos_mask[out.pos[c * n3 + i]];
+          uint8_t r = 0;
+          while (used & (1ull << r)) ++r;
+          out.cell_round[c] = r;
+          nr = std::max<uint8_t>(nr, r + 1);
+          for (int i = 0; i < n3; ++i) pos_mask[out.pos[c * n3 + i]] |= 1ull << r;
+        }
+        out.team_rounds[t] = nr;
+        continue;
+      }
+      // conflict-free packing into at most 64 passes
+      fill.clear();
+      std::vector<uint32_t> &passes = group_passes[t];
+      passes.clear();
+      std::vector<uint32_t> leftover;
+      for (size_t c = c0; c < c1; ++c) {
+        uint64_t used = 0;
+        for (int i = 0; i < n3; ++i) used |= pos_mask[out.pos[c * n3 + i]];
+        int pick = -1;
+        for (int q = 0; q < (int)fill.size(); ++q)
+          if (!(used & (1ull << q)) && fill[q] < cells_per_pass) { pick = q; break; }
+        if (pick < 0 && fill.size() < 64) { pick = (int)fill.size(); fill.push_back(0); passes.resize(passes.size() + cells_per_pass, 0xffffffffu); }
+        if (pick < 0) { leftover.push_back((uint32_t)c); continue; }
+        passes[(size_t)pick * cells_per_pass + fill[pick]++] = (uint32_t)c;
+        for (int i = 0; i < n3; ++i) pos_mask[out.pos[c * n3 + i]] |= 1ull << pick;
+      }
+      // cells that found no conflict-free pass: append to the emptiest passes, later rounds
+      uint8_t nr = 1;
+      for (uint32_t c : leftover) {
+        int pick = -1;
+        for (int q = 0; q < (int)fill.size(); ++q) if (fill[q] < cells_per_pass && (pick < 0 || fill[q] < fill[pick])) pick = q;
+        if (pick < 0) { pick = (int)fill.size(); fill.push_back(0); passes.resize(passes.size() + cells_per_pass, 0xffffffffu); }
+        // round = 1 + highest round among conflicting cells already in that pass (conservative: next round)
+        uint8_t r = 0;
+        for (int k = 0; k < fill[pick]; ++k) r = std::max<uint8_t>(r, out.cell_round[passes[(size_t)pick * cells_per_pass + k]] + 1);
+        out.cell_round[c] = r;
+        nr = std::max<uint8_t>(nr, r + 1);
+        passes[(size_t)pick * cells_per_pass + fill[pick]++] = c;
+      }
+      out.team_rounds[t] = nr;
+      // idle slots repeat the pass's first cell, flagged by bit 31
+      for (size_t q = 0; q < fill.size(); ++q)
+        for (int k = fill[q]; k < cells_per_pass; ++k) passes[q * cells_per_pass + k] = passes[q * cells_per_pass] | 0x80000000u;
+    }
+  }
+  if (cells_per_pass > 0) {
+    for (size_t t = 0; t < n_teams; ++t) out.pass_off[t + 1] = out.pass_off[t] + (uint32_t)(group_passes[t].size() / cells_per_pass);
+    out.pass_cell.resize((size_t)out.pass_off[n_teams] * cells_per_pass);
+    for (size_t t = 0; t < n_teams; ++t)
+      std::copy(group_passes[t].begin(), group_passes[t].end(), out.pass_cell.begin() + (size_t)out.pass_off[t] * cells_per_pass);
+  }
+  // shared DoFs: CSR over partial-slab slots
+  {
+    std::vector<uint32_t> cnt(n_local, 0);
+    for (size_t e = 0; e < out.dofs.size(); ++e)
+      if (!(out.dofs[e] & 0x80000000u)) ++cnt[out.dofs[e]];
+    std::vector<uint32_t> sh_index(n_local, 0xffffffffu);
+    for (size_t g = 0; g < n_local; ++g)
+      if (cnt[g]) { sh_index[g] = (uint32_t)out.sh_dof.size(); out.sh_dof.push_back((uint32_t)g); }
+    out.sh_off.assign(out.sh_dof.size() + 1, 0);
+    for (size_t k = 0; k < out.sh_dof.size(); ++k) out.sh_off[k + 1] = out.sh_off[k] + cnt[out.sh_dof[k]];
+    out.sh_slot.resize(out.sh_off.back());
+    std::vector<uint32_t> cur(out.sh_off.begin(), out.sh_off.end() - 1);
+    for (size_t e = 0; e < out.dofs.size(); ++e) // e ascends with the team index -> fixed summation order
+      if (!(out.dofs[e] & 0x80000000u)) out.sh_slot[cur[sh_index[out.dofs[e]]]++] = (uint32_t)e;
+  }
+  return BP5_OK;
+}
 } // namespace bp5
 
 using namespace bp5;
@@ -162,7 +298,7 @@ struct bp5_mesh {
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0;
   uint64_t n_global = 0;
   uint32_t ND[3] = {0, 0, 0};
-  std::vector<uint32_t> l2g, constrained, send_offsets, send_indices, recv_offsets;
+  std::vector<uint32_t> l2g, constrained, send_offsets, send_indices, recv_offsets, block_off;
   std::vector<double> coords;
   std::vector<uint64_t> gids;
   std::vector<int> neighbors;
@@ -195,27 +331,102 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   Tables t;
   shape_tables(p, BP5_QUAD_GLL, t);
 
+  // ---- local DoF numbering of the owned range [0,NX) x [0,NY) x [Kown0,Ktop]
+  const uint64_t zi0_ = z0 + (r > 0 ? 1 : 0);
+  const bool blocked_ = d->cell_block[0] && d->cell_block[1] && d->cell_block[2];
+  if (d->dof_numbering == 1 && !blocked_) { delete m; return fail(BP5_ERR_INVALID, "block-major numbering needs cell_block"); }
+  // per direction: slots are alternately block-boundary planes (length 1) and the runs between them
+  struct Dir {
+    std::vector<uint8_t> kind;      // per coordinate (relative to lo): 1 = plane, 0 = run
+    std::vector<uint32_t> slot, in; // slot index among its kind, offset inside the run
+    std::vector<uint64_t> L[2], Pre[2]; // per kind: lengths and exclusive prefix sums
+    uint64_t S[2] = {0, 0};
+  } dir[3];
+  auto build_dir = [&](Dir &D, uint64_t lo, uint64_t hi, const std::vector<uint64_t> &planes) {
+    const uint64_t N = hi - lo + 1;
+    D.kind.assign(N, 0); D.slot.assign(N, 0); D.in.assign(N, 0);
+    for (uint64_t q : planes) if (q >= lo && q <= hi) D.kind[q - lo] = 1;
+    uint32_t nrun = 0, nplane = 0;
+    uint64_t runlen = 0;
+    for (uint64_t x = 0; x < N; ++x) {
+      if (D.kind[x]) {
+        if (runlen) { D.L[0].push_back(runlen); ++nrun; runlen = 0; }
+        D.slot[x] = nplane++; D.L[1].push_back(1);
+      } else { D.slot[x] = nrun; D.in[x] = (uint32_t)runlen++; }
+    }
+    if (runlen) D.L[0].push_back(runlen);
+    for (int k = 0; k < 2; ++k) {
+      D.Pre[k].assign(D.L[k].size() + 1, 0);
+      for (size_t i = 0; i < D.L[k].size(); ++i) D.Pre[k][i + 1] = D.Pre[k][i] + D.L[k][i];
+      D.S[k] = D.Pre[k].back();
+    }
+  };
+  uint64_t class_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (d->dof_numbering == 1) {
+    std::vector<uint64_t> px, py, pz;
+    for (uint64_t X = 0; X < n0; X += d->cell_block[0]) px.push_back(p * X);
+    px.push_back(p * n0);
+    for (uint64_t Y = 0; Y < n1; Y += d->cell_block[1]) py.push_back(p * Y);
+    py.push_back(p * n1);
+    for (uint64_t Z = zi0_; Z < z1; Z += d->cell_block[2]) pz.push_back(p * Z);
+    pz.push_back(p * z1);
+    if (r > 0) pz.push_back(p * z0); // ghost plane: outside the owned range, ignored by build_dir
+    build_dir(dir[0], 0, NX - 1, px);
+    build_dir(dir[1], 0, NY - 1, py);
+    build_dir(dir[2], Kown0, Ktop, pz);
+    // classes ordered: interior, x-/y-/z-faces, edges, vertices; class id = kx + 2 ky + 4 kz
+    const int order[8] = {0, 1, 2, 4, 3, 5, 6, 7};
+    uint64_t base = 0;
+    for (int o = 0; o < 8; ++o) {
+      const int cl = order[o];
+      class_base[cl] = base;
+      base += dir[0].S[cl & 1] * dir[1].S[(cl >> 1) & 1] * dir[2].S[(cl >> 2) & 1];
+    }
+  }
   auto local_of = [&](uint64_t I, uint64_t J, uint64_t K) -> uint32_t {
-    if (K >= Kown0) return (uint32_t)(I + NX * (J + NY * (K - Kown0)));
-    return (uint32_t)(n_owned + I + NX * J); // ghost plane K == Kbot, owned by rank-1
+    if (K < Kown0) return (uint32_t)(n_owned + I + NX * J); // ghost plane K == Kbot, owned by rank-1
+    if (d->dof_numbering != 1) return (uint32_t)(I + NX * (J + NY * (K - Kown0)));
+    const uint64_t c3[3] = {I, J, K - Kown0};
+    int k[3]; uint64_t sl[3], in[3], Ls[3], Pr[3], Ss[3];
+    for (int e = 0; e < 3; ++e) {
+      k[e] = dir[e].kind[c3[e]]; sl[e] = dir[e].slot[c3[e]]; in[e] = dir[e].in[c3[e]];
+      Ls[e] = dir[e].L[k[e]][sl[e]]; Pr[e] = dir[e].Pre[k[e]][sl[e]]; Ss[e] = dir[e].S[k[e]];
+    }
+    const int cl = k[0] + 2 * k[1] + 4 * k[2];
+    // entities nested z outer, y, x inner; inside an entity x fastest
+    const uint64_t ent = Pr[2] * (Ss[1] * Ss[0]) + Ls[2] * (Pr[1] * Ss[0] + Ls[1] * Pr[0]);
+    return (uint32_t)(class_base[cl] + ent + in[0] + Ls[0] * (in[1] + Ls[1] * in[2]));
   };
 
-  // cells: layers not touching ghosts first, the ghost-touching bottom layer (r>0) last
+  // cells: layers not touching ghosts first, the ghost-touching bottom layer (r>0) last; inside
+  // each of the two regions cells are emitted brick by brick (desc.cell_block) so that consecutive
+  // cells form compact groups for the block-assembled operator kernel
   const size_t nl = (size_t)n * n * n;
   m->l2g.resize(n_cells * nl);
-  std::vector<uint64_t> layers;
-  for (uint64_t z = z0 + (r > 0 ? 1 : 0); z < z1; ++z) layers.push_back(z);
-  m->n_interior = (uint32_t)(layers.size() * n0 * n1);
-  if (r > 0) layers.push_back(z0);
+  const uint64_t zi0 = z0 + (r > 0 ? 1 : 0); // interior layers [zi0, z1)
+  m->n_interior = (uint32_t)((z1 - zi0) * n0 * n1);
+  const bool blocked = d->cell_block[0] && d->cell_block[1] && d->cell_block[2];
+  const uint64_t bx = blocked ? d->cell_block[0] : n0, by = blocked ? d->cell_block[1] : 1, bz = blocked ? d->cell_block[2] : 1;
   size_t c = 0;
-  for (uint64_t z : layers)
-    for (uint64_t y = 0; y < n1; ++y)
-      for (uint64_t x = 0; x < n0; ++x, ++c) {
-        uint32_t *dst = &m->l2g[c * nl];
-        for (int k = 0; k < n; ++k)
-          for (int j = 0; j < n; ++j)
-            for (int i = 0; i < n; ++i) dst[i + n * (j + n * k)] = local_of(p * x + i, p * y + j, p * z + k);
-      }
+  m->block_off.push_back(0);
+  auto emit_region = [&](uint64_t za, uint64_t zb) {
+    for (uint64_t Z = za; Z < zb; Z += bz)
+      for (uint64_t Y = 0; Y < n1; Y += by)
+        for (uint64_t X = 0; X < n0; X += bx) {
+          for (uint64_t z = Z; z < std::min(Z + bz, zb); ++z)
+            for (uint64_t y = Y; y < std::min(Y + by, n1); ++y)
+              for (uint64_t x = X; x < std::min(X + bx, n0); ++x, ++c) {
+                uint32_t *dst = &m->l2g[c * nl];
+                for (int k = 0; k < n; ++k)
+                  for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) dst[i + n * (j + n * k)] = local_of(p * x + i, p * y + j, p * z + k);
+              }
+          if (blocked) m->block_off.push_back((uint32_t)c);
+        }
+  };
+  emit_region(zi0, z1);
+  if (r > 0) emit_region(z0, z0 + 1);
+  if (!blocked) m->block_off.clear();
 
   // coordinates, global ids, constraints
   const uint64_t nloc = n_owned + n_ghost;
@@ -256,7 +467,8 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   }
   if (r < R - 1) { // neighbour r+1: we send our top plane, receive nothing
     m->neighbors.push_back(r + 1);
-    for (uint64_t q = 0; q < plane; ++q) m->send_indices.push_back((uint32_t)(n_owned - plane + q));
+    for (uint64_t J = 0; J < NY; ++J)
+      for (uint64_t I = 0; I < NX; ++I) m->send_indices.push_back(local_of(I, J, Ktop));
     m->send_offsets.push_back((uint32_t)m->send_indices.size());
     m->recv_offsets.push_back(m->recv_offsets.back());
   }
@@ -281,6 +493,8 @@ extern "C" int bp5_mesh_view_get(const bp5_mesh *m, bp5_mesh_view *v)
   v->send_offsets_host = m->send_offsets.data();
   v->send_indices_host = m->send_indices.data();
   v->recv_offsets_host = m->recv_offsets.data();
+  v->n_cell_blocks = m->block_off.empty() ? 0 : (uint32_t)m->block_off.size() - 1;
+  v->cell_block_offsets_host = m->block_off.empty() ? nullptr : m->block_off.data();
   return BP5_OK;
 }
 

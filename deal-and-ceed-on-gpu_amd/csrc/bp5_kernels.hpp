@@ -108,7 +108,9 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v)
 // ------------------------------------------------------------------------------------ fused operator
 // P degree, COLL: quadrature == GLL (N == I), TW waves per team, LPC lanes per cell slot,
 // TPB teams per block (TW > 1 requires TPB == 1), PF: prefetch all six planes before evaluate
-template <int P, bool COLL, int TW, int LPC, int TPB, bool PF>
+// ABL (timing-only ablation builds, wrong results): bit0 skip the scatter atomics, bit1 skip the
+// metric loads, bit2 skip the src gather, bit3 skip the contractions
+template <int P, bool COLL, int TW, int LPC, int TPB, bool PF, int ABL = 0>
 __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a, ShapeArg<P + 1> sh)
 {
   constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
 #pragma unroll
   for (int k = 0; k < n; ++k) idx[k] = l2g_c[k * n2];
 #pragma unroll
-  for (int k = 0; k < n; ++k) u[k] = a.src[idx[k]];
+  for (int k = 0; k < n; ++k) u[k] = (ABL & 4) ? 1e-9 * idx[k] : a.src[idx[k]];
 
   // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
   const double *cf = a.coef + cell * n3 + abm;
@@ -153,11 +155,14 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
 #pragma unroll
     for (int pl = 0; pl < 6; ++pl)
 #pragma unroll
-      for (int i = 0; i < n; ++i) S[pl][i] = cf[pl * a.plane_stride + i * n2];
+      for (int i = 0; i < n; ++i) S[pl][i] = (ABL & 2) ? 1.0 + pl + i + 1e-3 * abm : cf[pl * a.plane_stride + i * n2];
   }
 
   double g0[n], g1[n], g2[n];
-  if constexpr (!COLL) {
+  if constexpr (ABL & 8) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) { g0[i] = u[i]; g1[i] = 2.0 * u[i]; g2[i] = 3.0 * u[i]; }
+  } else if constexpr (!COLL) {
     // z-pass in registers
     double aN[n], aD[n];
     MV_N(sh.N, u, aN);
@@ -242,7 +247,10 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
 
   // ---- integrate (transpose sequence)
   double y[n];
-  if constexpr (!COLL) {
+  if constexpr (ABL & 8) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) y[i] = g0[i] + g1[i] + g2[i];
+  } else if constexpr (!COLL) {
     double e1[n], e2[n], e3[n];
     MV_DT(sh.D, g0, e1);
     MV_NT(sh.N, g1, e2);
@@ -300,11 +308,601 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
   }
 
   // ---- scatter-add (distribute_local_to_global, bp5/fe_evaluation_gl.h:170-180)
-  if (active) {
+  if constexpr (ABL & 1) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < n; ++k) acc += y[k];
+    if (acc == 1.2345e300) a.dst[idx[0]] = acc; // keeps y live, never taken
+  } else if (active) {
 #pragma unroll
     for (int k = 0; k < n; ++k) atomic_add_f64(a.dst + idx[k], y[k]);
   }
 #undef TL
+}
+
+// ------------------------------------------------------------------------------------ fused operator, team-assembled
+// Same arithmetic as apply_pencil_kernel, but gather and scatter go through the team's LDS:
+//   * the host builds, per team of CPT consecutive cells, the sorted list of the distinct DoFs the
+//     team touches (tp.dofs) and for every local DoF its 16-bit position in that list (tp.pos);
+//   * gather: the team reads src through the sorted list (contiguous runs -> coalesced) into LDS,
+//     lanes pick their values by position;
+//   * scatter: lanes accumulate into an LDS vector (ds_add_f64), then the team issues ONE global
+//     atomic per distinct DoF, consecutive lanes on consecutive sorted indices, so a 64-byte
+//     atomic request carries up to 8 contributions instead of ~3 and shared faces inside the team
+//     are pre-summed.  (v1 was bound by the chip-wide atomic request rate: profiles/r1.)
+// The staging vectors alias the transpose tiles (they are live before / after the tile phase).
+struct TeamPlan {
+  const uint32_t *off;        // [n_teams_total + 1]
+  const uint32_t *dofs;       // sorted distinct local DoF indices per team; bit 31: touched by this team only
+  const uint16_t *pos;        // [n_cells * n^3] position of each local DoF in its team's list
+  const uint8_t *cell_round;  // [n_cells] accumulation round of the cell inside its team
+  const uint8_t *team_rounds; // [n_teams_total] number of rounds
+  double *partial;            // [off[n_teams_total]] per-(team, DoF) partial sums of shared DoFs
+};
+
+// Scatter modes of the team kernel
+//   SC_ATOMIC     dst += via one global atomic per distinct DoF (any cell range)
+//   SC_OWNER_SET  team-exclusive DoFs: dst = sum (plain store); shared DoFs: partial slab
+//   SC_OWNER_ADD  same with dst += for the exclusive DoFs
+// The OWNER modes need every team of the plan to run in the launch; combine_kernel then finishes
+// the shared DoFs in a fixed order, so the whole operator is free of atomics and bitwise
+// reproducible.
+enum { SC_ATOMIC = 0, SC_OWNER_SET = 1, SC_OWNER_ADD = 2 };
+
+__device__ __forceinline__ void lds_add_f64(double *p, double v)
+{
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int P, bool COLL, int TW, int LPC, bool PF, int SCATTER, int ABL = 0>
+__global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPlan tp, ShapeArg<P + 1> sh)
+{
+  constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
+  constexpr int TEAM = 64 * TW;
+  constexpr int CPT = TEAM / LPC;
+  constexpr int MAXU = (CPT * n3 + TEAM - 1) / TEAM; // list entries per thread
+  static_assert(LPC >= n2 && CPT >= 1, "lanes per cell");
+  using L = LdsLayout<n, LPC>;
+  static_assert(CPT * L::CS >= CPT * n3, "staging vectors must fit in the tile region");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int t = threadIdx.x;
+  const int c = t / LPC, ab = t - c * LPC;
+  const uint32_t blk = (blockIdx.x & 7u) * a.teams_per_xcd + (blockIdx.x >> 3);
+  if (blk >= a.n_teams) return;                      // whole block: no barrier is skipped by a subset
+  const uint32_t team = a.cell_begin / CPT + blk;    // teams are aligned to multiples of CPT cells
+  const uint64_t cell_raw = (uint64_t)team * CPT + c;
+  const bool active = (ab < n2) && (c < CPT) && (cell_raw >= a.cell_begin) && (cell_raw < a.cell_end);
+  const uint64_t cell = cell_raw < a.cell_end ? cell_raw : (uint64_t)a.cell_end - 1;
+  const int abm = ab < n2 ? ab : ab % n2;
+  const int a_ = abm % n, b_ = abm / n;
+  double *T = lds + (c < CPT ? c : 0) * L::CS;
+#define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]
+
+  // ---- stage the team's distinct src values in LDS (sorted indices: contiguous runs)
+  const uint32_t o0 = tp.off[team];
+  const int m = (int)(tp.off[team + 1] - o0);
+  uint32_t gidx[MAXU];
+#pragma unroll
+  for (int r = 0; r < MAXU; ++r) {
+    const int i = t + r * TEAM;
+    gidx[r] = i < m ? tp.dofs[o0 + i] : 0u;
+  }
+  const int my_round = tp.cell_round[cell];
+  const int n_rounds = tp.team_rounds[team];
+  // ---- metric planes (issued early; consumed after the evaluate phase)
+  const double *cf = a.coef + cell * n3 + abm;
+  double S[PF ? 6 : 1][n];
+  if constexpr (PF) {
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl)
+#pragma unroll
+      for (int i = 0; i < n; ++i) S[pl][i] = cf[pl * a.plane_stride + i * n2];
+  }
+  uint16_t ps[n];
+  const uint16_t *pos_c = tp.pos + cell * n3 + abm;
+#pragma unroll
+  for (int k = 0; k < n; ++k) ps[k] = pos_c[k * n2];
+  double u[n];
+  if constexpr (ABL & 4) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) u[k] = 1e-9 * (ps[k] + gidx[k % MAXU]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < MAXU; ++r) {
+      const int i = t + r * TEAM;
+      if (i < m) lds[i] = a.src[gidx[r] & 0x7fffffffu];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < n; ++k) u[k] = lds[ps[k]];
+    __syncthreads();
+  }
+
+  double g0[n], g1[n], g2[n];
+  if constexpr (!COLL) {
+    double aN[n], aD[n];
+    MV_N(sh.N, u, aN);
+    MV_D(sh.D, u, aD);
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = aN[k]; TL(1, k, b_, a_) = aD[k]; }
+    }
+    __syncthreads();
+    double vN[n], vD[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) { vN[j] = TL(0, b_, j, a_); vD[j] = TL(1, b_, j, a_); }
+    double c1[n], c2[n], c3[n];
+    MV_N(sh.N, vN, c1);
+    MV_D(sh.D, vN, c2);
+    MV_N(sh.N, vD, c3);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = c1[j]; TL(1, b_, j, a_) = c2[j]; TL(2, b_, j, a_) = c3[j]; }
+    }
+    __syncthreads();
+    double r1[n], r2[n], r3[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { r1[i] = TL(0, b_, a_, i); r2[i] = TL(1, b_, a_, i); r3[i] = TL(2, b_, a_, i); }
+    MV_D(sh.D, r1, g0);
+    MV_N(sh.N, r2, g1);
+    MV_N(sh.N, r3, g2);
+  } else {
+    double gz[n];
+    MV_D(sh.D, u, gz);
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = u[k]; TL(2, k, b_, a_) = gz[k]; }
+    }
+    __syncthreads();
+    double vN[n], c2[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) vN[j] = TL(0, b_, j, a_);
+    MV_D(sh.D, vN, c2);
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < n; ++j) TL(1, b_, j, a_) = c2[j];
+    }
+    __syncthreads();
+    double r1[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { r1[i] = TL(0, b_, a_, i); g1[i] = TL(1, b_, a_, i); g2[i] = TL(2, b_, a_, i); }
+    MV_D(sh.D, r1, g0);
+  }
+
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double s00, s11, s22, s01, s02, s12;
+    if constexpr (PF) {
+      s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
+    } else {
+      s00 = cf[0 * a.plane_stride + i * n2]; s11 = cf[1 * a.plane_stride + i * n2]; s22 = cf[2 * a.plane_stride + i * n2];
+      s01 = cf[3 * a.plane_stride + i * n2]; s02 = cf[4 * a.plane_stride + i * n2]; s12 = cf[5 * a.plane_stride + i * n2];
+    }
+    const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
+    g0[i] = s00 * x0 + s01 * x1 + s02 * x2;
+    g1[i] = s01 * x0 + s11 * x1 + s12 * x2;
+    g2[i] = s02 * x0 + s12 * x1 + s22 * x2;
+  }
+
+  double y[n];
+  if constexpr (!COLL) {
+    double e1[n], e2[n], e3[n];
+    MV_DT(sh.D, g0, e1);
+    MV_NT(sh.N, g1, e2);
+    MV_NT(sh.N, g2, e3);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = e2[i]; TL(2, b_, a_, i) = e3[i]; }
+    }
+    __syncthreads();
+    double w1[n], w2[n], w3[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); w3[j] = TL(2, b_, j, a_); }
+    double f1[n], f2[n];
+    MV_NT(sh.N, w1, f1);
+    MV_DT_ADD(sh.D, w2, f1);
+    MV_NT(sh.N, w3, f2);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = f1[j]; TL(1, b_, j, a_) = f2[j]; }
+    }
+    __syncthreads();
+    double z1[n], z2[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) { z1[k] = TL(0, k, b_, a_); z2[k] = TL(1, k, b_, a_); }
+    MV_NT(sh.N, z1, y);
+    MV_DT_ADD(sh.D, z2, y);
+  } else {
+    double e1[n];
+    MV_DT(sh.D, g0, e1);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = g1[i]; TL(2, b_, a_, i) = g2[i]; }
+    }
+    __syncthreads();
+    double w1[n], w2[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); }
+    MV_DT_ADD(sh.D, w2, w1);
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < n; ++j) TL(0, b_, j, a_) = w1[j];
+    }
+    __syncthreads();
+    double z2[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) { y[k] = TL(0, k, b_, a_); z2[k] = TL(2, k, b_, a_); }
+    MV_DT_ADD(sh.D, z2, y);
+  }
+
+  // ---- team-level assembly in LDS.  Cells of one round share no DoF (host colouring), so
+  //      plain read-modify-write is race-free and the summation order is fixed.
+  if constexpr (ABL & 1) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < n; ++k) acc += y[k];
+    if (acc == 1.2345e300) a.dst[gidx[0] & 0x7fffffffu] = acc + my_round + n_rounds; // keeps y live, never taken
+    return;
+  }
+  __syncthreads(); // every tile read is done: the region becomes the accumulator
+#pragma unroll
+  for (int r = 0; r < MAXU; ++r) {
+    const int i = t + r * TEAM;
+    if (i < m) lds[i] = 0.0;
+  }
+  __syncthreads();
+  for (int rd = 0; rd < n_rounds; ++rd) {
+    if (active && my_round == rd) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) lds[ps[k]] += y[k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < MAXU; ++r) {
+    const int i = t + r * TEAM;
+    if (i < m) {
+      const double v = lds[i];
+      const uint32_t g = gidx[r];
+      if constexpr (SCATTER == SC_ATOMIC) {
+        atomic_add_f64(a.dst + (g & 0x7fffffffu), v);
+      } else {
+        if (g & 0x80000000u) {
+          if constexpr (SCATTER == SC_OWNER_SET) a.dst[g & 0x7fffffffu] = v;
+          else a.dst[g & 0x7fffffffu] += v;
+        } else
+          tp.partial[o0 + i] = v;
+      }
+    }
+  }
+#undef TL
+}
+
+// ------------------------------------------------------------------------------------ fused operator, block-assembled
+// One 256-thread workgroup owns a compact brick of cells (e.g. 4x4x4) and walks it in passes of
+// CPT cells.  Contributions are summed into an LDS accumulator that spans the brick's distinct
+// DoFs; after the last pass DoFs touched by this brick only are stored with plain stores and
+// the brick-surface DoFs go to a per-brick partial slab that combine_kernel sums in a fixed
+// order: no global atomics, no zero-fill of dst, bitwise reproducible.
+// The accumulator limits residency to two workgroups per CU, so memory latency is hidden by
+// software pipelining instead of occupancy: while pass q computes, the indices, the gathered src
+// values and all six metric planes of pass q+1 are already in flight into a second register set
+// (the kernel may use the full 256 VGPRs at 2 waves per SIMD).
+struct BlockPlan {
+  const uint32_t *pass_cell;  // [n_passes * CPT] cell id per slot; bit 31: idle slot (id still valid)
+  const uint32_t *pass_off;   // [n_blocks+1] first pass of each block
+  const uint32_t *off;        // [n_blocks+1] offsets into dofs / partial
+  const uint32_t *dofs;       // sorted distinct DoFs per block; bit 31: touched by this block only
+  const uint16_t *pos;        // [n_cells*n^3] position of each local DoF in its block's list
+  const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
+  const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
+  double *partial;            // [off[n_blocks]]
+  uint32_t n_blocks, n_wg;    // persistent workgroups, n_wg a multiple of 8
+};
+
+// register set of one pass (cell ids, positions, gathered values, metric)
+template <int n>
+struct PassRegs {
+  uint16_t ps[n];
+  double u[n];
+  double S[6][n];
+  uint32_t idx[n];
+  uint32_t ent; // pass_cell entry
+  int round;
+  bool active;
+};
+
+template <int P, bool COLL, int LPC, int SCATTER, int ABL>
+struct BlockPass {
+  static constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
+  static constexpr int TEAM = 256;
+  static constexpr int CPT = TEAM / LPC;
+  using L = LdsLayout<n, LPC>;
+  using R = PassRegs<n>;
+
+  // issue index / position / metric loads of the cell named by r.ent
+  static __device__ __forceinline__ void issue_loads(const ApplyArgs &a, const BlockPlan &bp, R &r, int abm, bool lane_ok, bool exists)
+  {
+    r.active = lane_ok && exists && !(r.ent >> 31);
+    const uint64_t cell = r.ent & 0x7fffffffu;
+    const uint32_t *l2g_c = a.l2g + cell * n3 + abm;
+    const uint16_t *pos_c = bp.pos + cell * n3 + abm;
+#pragma unroll
+    for (int k = 0; k < n; ++k) r.idx[k] = l2g_c[k * n2];
+#pragma unroll
+    for (int k = 0; k < n; ++k) r.ps[k] = pos_c[k * n2];
+    r.round = bp.cell_round[cell];
+    const double *cf = a.coef + cell * n3 + abm;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl)
+#pragma unroll
+      for (int i = 0; i < n; ++i) r.S[pl][i] = (ABL & 2) ? 1.0 + pl + i : cf[pl * a.plane_stride + i * n2];
+  }
+  static __device__ __forceinline__ void issue_gather(const ApplyArgs &a, R &r)
+  {
+#pragma unroll
+    for (int k = 0; k < n; ++k) r.u[k] = (ABL & 4) ? 1e-9 * r.idx[k] : a.src[r.idx[k]];
+  }
+
+  // one pass: compute with `cur`, keep the loads of `nxt` in flight.  Returns nothing; all
+  // block bookkeeping is done by the caller.
+  static __device__ __forceinline__ void run(const ApplyArgs &a, const ShapeArg<n> &sh, R &cur, R &nxt, double *T, double *acc, int a_, int b_,
+                                             int n_rounds)
+  {
+#define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]
+    const bool active = cur.active;
+    double(&u)[n] = cur.u;
+    double g0[n], g1[n], g2[n];
+    if constexpr (ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { g0[i] = u[i]; g1[i] = 2.0 * u[i]; g2[i] = 3.0 * u[i]; }
+    } else if constexpr (!COLL) {
+      double aN[n], aD[n];
+      MV_N(sh.N, u, aN);
+      MV_D(sh.D, u, aD);
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = aN[k]; TL(1, k, b_, a_) = aD[k]; }
+      }
+      __syncthreads();
+      double vN[n], vD[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) { vN[j] = TL(0, b_, j, a_); vD[j] = TL(1, b_, j, a_); }
+      double c1[n], c2[n], c3[n];
+      MV_N(sh.N, vN, c1);
+      MV_D(sh.D, vN, c2);
+      MV_N(sh.N, vD, c3);
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = c1[j]; TL(1, b_, j, a_) = c2[j]; TL(2, b_, j, a_) = c3[j]; }
+      }
+      __syncthreads();
+      double r1[n], r2[n], r3[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) { r1[i] = TL(0, b_, a_, i); r2[i] = TL(1, b_, a_, i); r3[i] = TL(2, b_, a_, i); }
+      MV_D(sh.D, r1, g0);
+      MV_N(sh.N, r2, g1);
+      MV_N(sh.N, r3, g2);
+    } else {
+      double gz[n];
+      MV_D(sh.D, u, gz);
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = u[k]; TL(2, k, b_, a_) = gz[k]; }
+      }
+      __syncthreads();
+      double vN[n], c2[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) vN[j] = TL(0, b_, j, a_);
+      MV_D(sh.D, vN, c2);
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) TL(1, b_, j, a_) = c2[j];
+      }
+      __syncthreads();
+      double r1[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) { r1[i] = TL(0, b_, a_, i); g1[i] = TL(1, b_, a_, i); g2[i] = TL(2, b_, a_, i); }
+      MV_D(sh.D, r1, g0);
+    }
+
+    // the index loads of the next pass have landed by now: start its src gather
+    issue_gather(a, nxt);
+
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
+      g0[i] = cur.S[0][i] * x0 + cur.S[3][i] * x1 + cur.S[4][i] * x2;
+      g1[i] = cur.S[3][i] * x0 + cur.S[1][i] * x1 + cur.S[5][i] * x2;
+      g2[i] = cur.S[4][i] * x0 + cur.S[5][i] * x1 + cur.S[2][i] * x2;
+    }
+
+    double y[n];
+    if constexpr (ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) y[i] = g0[i] + g1[i] + g2[i];
+    } else if constexpr (!COLL) {
+      double e1[n], e2[n], e3[n];
+      MV_DT(sh.D, g0, e1);
+      MV_NT(sh.N, g1, e2);
+      MV_NT(sh.N, g2, e3);
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = e2[i]; TL(2, b_, a_, i) = e3[i]; }
+      }
+      __syncthreads();
+      double w1[n], w2[n], w3[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); w3[j] = TL(2, b_, j, a_); }
+      double f1[n], f2[n];
+      MV_NT(sh.N, w1, f1);
+      MV_DT_ADD(sh.D, w2, f1);
+      MV_NT(sh.N, w3, f2);
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = f1[j]; TL(1, b_, j, a_) = f2[j]; }
+      }
+      __syncthreads();
+      double z1[n], z2[n];
+#pragma unroll
+      for (int k = 0; k < n; ++k) { z1[k] = TL(0, k, b_, a_); z2[k] = TL(1, k, b_, a_); }
+      MV_NT(sh.N, z1, y);
+      MV_DT_ADD(sh.D, z2, y);
+    } else {
+      double e1[n];
+      MV_DT(sh.D, g0, e1);
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = g1[i]; TL(2, b_, a_, i) = g2[i]; }
+      }
+      __syncthreads();
+      double w1[n], w2[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); }
+      MV_DT_ADD(sh.D, w2, w1);
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) TL(0, b_, j, a_) = w1[j];
+      }
+      __syncthreads();
+      double z2[n];
+#pragma unroll
+      for (int k = 0; k < n; ++k) { y[k] = TL(0, k, b_, a_); z2[k] = TL(2, k, b_, a_); }
+      MV_DT_ADD(sh.D, z2, y);
+    }
+
+    // accumulate into the block's LDS vector; cells of one round share no DoF (normally the
+    // whole pass is one round: host packing, bp5_host.cpp)
+    if constexpr (!(ABL & 1)) {
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        if (active && cur.round == rd) {
+#pragma unroll
+          for (int k = 0; k < n; ++k) acc[cur.ps[k]] += y[k];
+        }
+        __syncthreads();
+      }
+    } else {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) sacc += y[k];
+      if (sacc == 1.2345e300) acc[cur.ps[0]] = sacc;
+      __syncthreads();
+    }
+#undef TL
+  }
+};
+
+template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
+__global__ void __launch_bounds__(256, 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+{
+  using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
+  constexpr int n = P + 1, n2 = n * n;
+  constexpr int TEAM = 256;
+  constexpr int CPT = TEAM / LPC;
+  static_assert(LPC >= n2 && CPT >= 1, "lanes per cell");
+  using L = LdsLayout<n, LPC>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *acc = lds + CPT * L::CS; // accumulator behind the transpose tiles
+
+  const int t = threadIdx.x;
+  const int c = t / LPC, ab = t - c * LPC;
+  // persistent workgroup w owns the contiguous block range [b0,b1); workgroups that share an XCD
+  // (blockIdx % 8, speed only) own neighbouring ranges
+  const uint32_t w = (blockIdx.x & 7u) * (bp.n_wg >> 3) + (blockIdx.x >> 3);
+  uint32_t b = (uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg);
+  const uint32_t b1 = (uint32_t)((uint64_t)(w + 1) * bp.n_blocks / bp.n_wg);
+  if (b >= b1) return;
+  uint32_t gp = bp.pass_off[b];
+  const uint32_t gp_end = bp.pass_off[b1];
+  uint32_t boundary = bp.pass_off[b + 1];
+  uint32_t o0 = bp.off[b];
+  int m = (int)(bp.off[b + 1] - o0);
+  int n_rounds = bp.blk_rounds[b];
+  const bool lane_ok = (ab < n2) && (c < CPT);
+  const int abm = ab < n2 ? ab : ab % n2;
+  const int slot = c < CPT ? c : 0;
+  const int a_ = abm % n, b_ = abm / n;
+  double *T = lds + slot * L::CS;
+
+  for (int i = t; i < m; i += TEAM) acc[i] = 0.0;
+  __syncthreads();
+
+  auto entry = [&](uint32_t pass) { return bp.pass_cell[(uint64_t)(pass < gp_end ? pass : gp_end - 1) * CPT + slot]; };
+
+  // two register sets, used alternately (loop unrolled by two): the loads of pass q+1 are issued
+  // at the top of pass q and first waited for inside pass q+1
+  PassRegs<n> A, B;
+  A.ent = entry(gp);
+  B.ent = entry(gp + 1);
+  BP::issue_loads(a, bp, A, abm, lane_ok, true);
+  BP::issue_gather(a, A);
+
+  // end-of-pass bookkeeping: when a block is finished, write it out and re-arm the accumulator
+  auto finish_pass = [&]() {
+    if (gp + 1 == boundary) {
+      if constexpr (!(ABL & 1)) {
+        // the list entries are loaded eight at a time so that their latency is paid once per
+        // batch, not once per entry
+        for (int base = t; base < m; base += 8 * TEAM) {
+          uint32_t gl[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) gl[r] = (base + r * TEAM < m) ? bp.dofs[o0 + base + r * TEAM] : 0u;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int i = base + r * TEAM;
+            if (i < m) {
+              const uint32_t g = gl[r];
+              const double v = acc[i];
+              if (g & 0x80000000u) {
+                if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[g & 0x7fffffffu] = v; }
+                else if constexpr (SCATTER == SC_OWNER_SET) __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
+                else a.dst[g & 0x7fffffffu] += v;
+              } else {
+                if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
+                else __builtin_nontemporal_store(v, bp.partial + o0 + i);
+              }
+            }
+          }
+        }
+      }
+      ++b;
+      if (b < b1) {
+        boundary = bp.pass_off[b + 1];
+        o0 = bp.off[b];
+        m = (int)(bp.off[b + 1] - o0);
+        const int nr = bp.blk_rounds[b];
+        __syncthreads(); // the old sums have been read
+        for (int i = t; i < m; i += TEAM) acc[i] = 0.0;
+        __syncthreads();
+        n_rounds = nr;
+      }
+    }
+    ++gp;
+  };
+
+  while (gp < gp_end) {
+    A.ent = A.ent; // (A holds pass gp)
+    BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end);
+    const uint32_t entA2 = entry(gp + 2);
+    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds);
+    finish_pass();
+    if (gp >= gp_end) break;
+    A.ent = entA2;
+    BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
+    const uint32_t entB2 = entry(gp + 2);
+    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds);
+    finish_pass();
+    B.ent = entB2;
+  }
 }
 
 // ------------------------------------------------------------------------------------ generic 3-D layout
@@ -485,6 +1083,20 @@ __global__ void __launch_bounds__(n *n *n) l2norm_kernel(const uint32_t *l2g, co
     for (int m = 0; m < n3; ++m) s += t1[m];
     atomic_add_f64(out, s);
   }
+}
+
+// shared DoFs of the OWNER scatter modes: dst[g] (+)= sum of the teams' partials, fixed order
+template <bool ADD>
+__global__ void __launch_bounds__(256) combine_kernel(const uint32_t *sh_dof, const uint32_t *sh_off, const uint32_t *sh_slot,
+                                                     const double *partial, double *dst, uint32_t n_shared)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_shared) return;
+  const uint32_t b = sh_off[i], e = sh_off[i + 1];
+  double s = partial[sh_slot[b]];
+  for (uint32_t j = b + 1; j < e; ++j) s += partial[sh_slot[j]];
+  const uint32_t g = sh_dof[i];
+  if (ADD) dst[g] += s; else dst[g] = s;
 }
 
 // ------------------------------------------------------------------------------------ small vector kernels
@@ -681,13 +1293,14 @@ __global__ void __launch_bounds__(VB) cg_direction_kernel(double *d, const doubl
 }
 
 // ---- merged CG (SolverCGFullMerge, bp5/solver.h), schedule fixed
-// MODE 0: update_a0 (solver.h:48-72)    p = -D r ; v = 0
-// MODE 1: update_a<false> (:74-104)     r += alpha v ; p = beta p - D r ; v = 0
+// MODE 0: update_a0 (solver.h:48-72)    p = -D r
+// MODE 1: update_a<false> (:74-104)     r += alpha v ; p = beta p - D r
+// (the reference also zeroes v here for its atomic scatter; our operator overwrites v instead)
 // MODE 2: update_a1 (:106-140)          x += (alpha + ao/bo) p + (ao/bo) D r_old ; then as MODE 1
 // If the solve finished in the previous iteration with an x update pending, the kernel performs
 // the epilogue (solver.h:510-526) instead: odd it: x += alpha p ; even it: update_c (:315-336).
 template <int MODE>
-__global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, double *v, double *x, const double *diag, size_t n,
+__global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, const double *v, double *x, const double *diag, size_t n,
                                                        const double *sc, const int *st)
 {
   const bool done = st[ST_DONE];
@@ -705,14 +1318,12 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, do
     }
     if (MODE == 0) {
       p[i] = -di * r[i];
-      v[i] = 0.0;
     } else {
       const double r_old = r[i], p_old = p[i];
       if (MODE == 2) x[i] += (alpha + aob) * p_old + aob * di * r_old;
       const double rn = r_old + alpha * v[i];
       r[i] = rn;
       p[i] = beta * p_old - di * rn;
-      v[i] = 0.0;
     }
   }
 }

@@ -94,6 +94,10 @@ class MatrixFree:
         d.neighbor_rank_host, d.send_offsets_host = keep[3].ctypes.data, keep[4].ctypes.data
         d.send_indices_host, d.recv_offsets_host = keep[5].ctypes.data, keep[6].ctypes.data
         d.device, d.stream = device, stream
+        blocks = getattr(mesh, "cell_block_offsets", None)
+        if blocks is not None:
+            keep.append(np.ascontiguousarray(blocks, dtype=np.uint32))
+            d.n_cell_blocks, d.cell_block_offsets_host = keep[-1].size - 1, keep[-1].ctypes.data
         h = C.c_void_p()
         _lib.check(L.bp5_mf_create(C.byref(d), C.byref(h)))
         self._h = h

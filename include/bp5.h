@@ -70,6 +70,14 @@ typedef struct {
   double h;            /* cell side (reference: 2^-refine) */
   double deform_amp;   /* 0 = cubes; >0 = smooth boundary-preserving sine displacement */
   int rank, n_ranks;   /* z-slab decomposition; interface planes owned by the lower rank */
+  uint32_t cell_block[3]; /* cells are emitted block by block (bx x by x bz cells, x fastest inside a
+                             block) so that consecutive cells form compact bricks; 0 = plain
+                             lexicographic order */
+  int dof_numbering;   /* 0: lexicographic I + NX (J + NY K) over the owned range;
+                          1: block-major (needs cell_block): the DoFs strictly inside a cell block are
+                             numbered contiguously, then block faces, edges, vertices -- every entity
+                             contiguous.  A brick's gather/scatter then touches a few long runs instead
+                             of many short rows.  global_ids_host always gives the lexicographic id. */
 } bp5_mesh_desc;
 
 typedef struct {
@@ -91,6 +99,8 @@ typedef struct {
   const uint32_t *send_offsets_host;    /* [n_neighbors+1] into send_indices                    */
   const uint32_t *send_indices_host;    /* owned local indices                                  */
   const uint32_t *recv_offsets_host;    /* [n_neighbors+1] offsets into the ghost range         */
+  uint32_t n_cell_blocks;               /* cell blocks: block b = cells [off[b], off[b+1])       */
+  const uint32_t *cell_block_offsets_host; /* [n_cell_blocks+1]                                  */
 } bp5_mesh_view;
 
 int bp5_mesh_create_brick(const bp5_mesh_desc *desc, bp5_mesh **out);
@@ -125,6 +135,10 @@ typedef struct {
   const uint32_t *send_offsets_host, *send_indices_host, *recv_offsets_host;
   int device;              /* HIP device ordinal                                                */
   void *stream;            /* hipStream_t; NULL = the HIP default (null) stream                 */
+  /* optional: groups of consecutive cells that one workgroup assembles in LDS (compact bricks give
+   * the fewest DoFs shared between groups); NULL = the library groups 64 consecutive cells      */
+  uint32_t n_cell_blocks;
+  const uint32_t *cell_block_offsets_host; /* [n_cell_blocks+1], first 0, last n_cells           */
 } bp5_mf_desc;
 
 /* == MatrixFree::reinit(mapping, dof_handler, constraints, quad, additional_data),

@@ -112,3 +112,47 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", "Makefile")):
                 text = open(os.path.join(dp, f)).read()
                 assert "bp5_oracle" not in text and "c_oracle" not in text and "orc_" not in text, os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("p,cells,block,n_ranks", [(4, (8, 8, 8), (4, 4, 4), 1), (2, (7, 6, 5), (4, 4, 2), 1), (3, (5, 4, 6), (2, 2, 2), 2),
+                                                   (1, (4, 4, 9), (2, 2, 2), 3)])
+def test_block_major_numbering(p, cells, block, n_ranks):
+    """dof_numbering = 1: a permutation of the lexicographic numbering in which the DoFs strictly
+    inside a cell block are contiguous; everything else (coordinates, constraints, halo plan,
+    cell connectivity) is consistent with the lexicographic oracle mesh through global_ids."""
+    o = O.BrickMesh(p, cells, deform_amp=0.03)
+    cell_sets = {tuple(sorted(row)) for row in o.l2g.astype(np.int64)}
+    all_owned = []
+    for r in range(n_ranks):
+        m = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=r, n_ranks=n_ranks, cell_block=block, dof_numbering=1)
+        g = m.global_ids.astype(np.int64)
+        assert len(np.unique(g)) == m.n_local                      # numbering is injective
+        all_owned.append(g[:m.n_owned])
+        assert np.abs(m.coords - o.coords[g]).max() < 1e-14
+        assert set(g[m.constrained.astype(np.int64)]) == set(o.constrained.astype(np.int64)) & set(g)
+        n3 = (p + 1) ** 3
+        for row in m.l2g.astype(np.int64):
+            assert tuple(sorted(g[row])) in cell_sets
+        # in-cell lexicographic order is preserved: x fastest
+        row = m.l2g[0].astype(np.int64)
+        G = g[row]
+        NX = p * cells[0] + 1
+        assert G[1] - G[0] == 1 and G[p + 1] - G[0] == NX
+        # block interiors are contiguous index ranges
+        off = m.cell_block_offsets
+        for b in range(min(len(off) - 1, 6)):
+            dofs = np.unique(m.l2g[off[b]:off[b + 1]].ravel())
+            others = np.unique(np.concatenate([m.l2g[:off[b]].ravel(), m.l2g[off[b + 1]:].ravel()])) if m.n_cells > off[b + 1] - off[b] else np.zeros(0, np.uint32)
+            excl = np.setdiff1d(dofs, others)
+            excl = np.sort(excl[excl < m.n_owned]).astype(np.int64)
+            if off[b + 1] - off[b] == block[0] * block[1] * block[2] and len(excl):   # a full brick
+                runs = np.split(excl, np.where(np.diff(excl) != 1)[0] + 1)
+                want = (p * block[0] - 1) * (p * block[1] - 1) * (p * block[2] - 1)
+                assert max(len(r_) for r_ in runs) >= want
+        assert (m.send_indices < m.n_owned).all() and int(m.recv_offsets[-1]) == m.n_ghost
+        if r < n_ranks - 1:                                       # the sent plane is this rank's top DoF plane
+            NY, NZ = p * cells[1] + 1, p * cells[2] + 1
+            sent = g[m.send_indices.astype(np.int64)]
+            assert len(sent) == NX * NY and len(set(sent // (NX * NY))) == 1
+    allowned = np.concatenate(all_owned)
+    assert len(allowned) == o.n_dofs and len(np.unique(allowned)) == o.n_dofs

@@ -91,7 +91,9 @@ def test_cell_loop_all_degrees(p, quad):
     assert rel(dst.cpu().numpy(), ref) < TOL_OP
 
 
-@pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1)])
+@pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1),
+                                       (1, 10), (2, 10), (3, 10), (4, 10), (4, 11), (4, 12), (4, 13), (5, 10), (6, 10), (7, 10), (8, 10),
+                                       (1, 50), (2, 50), (3, 50), (4, 50), (4, 51), (5, 50), (6, 50), (7, 50), (8, 50), (4, 110)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_kernel_variants(p, variant, quad):
     cells = (7, 3, 1) if p <= 5 else (5, 1, 1)
@@ -107,12 +109,15 @@ def test_kernel_variants(p, variant, quad):
     assert rel(dst.cpu().numpy(), ref) < TOL_OP
 
 
-def test_cell_ranges_and_accumulation():
-    """cell_loop accumulates (do_zero_out = false semantics) and ranges compose."""
+@pytest.mark.parametrize("variant", [0, 3, 10, 11, 50])
+def test_cell_ranges_and_accumulation(variant):
+    """cell_loop accumulates (do_zero_out = false semantics) and ranges compose (ranges that cut
+    through a team exercise the masked-cell path of the team kernel)."""
     p, cells = 4, (4, 3, 2)
     pr = O.Problem(p, cells, 0)
     mesh = pkg.BrickMesh(p, cells)
     mf = pkg.MatrixFree().reinit(mesh, 0)
+    mf.set_apply_variant(variant)
     coef = mf.evaluate_coefficients()
     s = O.deterministic_src(mesh.n_owned, seed=11)
     dst = mf.initialize_dof_vector()
@@ -128,6 +133,55 @@ def test_cell_ranges_and_accumulation():
         mf.cell_loop(coef, src, dst, 0, mesh.n_cells + 1)
     with pytest.raises(pkg.BP5Error):
         mf.cell_loop(coef, src, src)
+
+
+@pytest.mark.parametrize("numbering", [0, 1])
+@pytest.mark.parametrize("p,cells,block,quad", [(4, (6, 5, 4), (4, 4, 2), 0), (4, (8, 8, 8), (4, 4, 4), 1), (2, (7, 6, 5), (4, 4, 4), 0),
+                                                (6, (3, 3, 2), (2, 2, 2), 0), (8, (2, 2, 2), (2, 2, 2), 1)])
+def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
+    """Block-assembled kernel on a mesh whose cells are ordered brick by brick (partial bricks at
+    the domain edges), with lexicographic and block-major DoF numbering: overwrite and accumulate
+    modes, bitwise run-to-run reproducibility, CG."""
+    torch = _t()
+    pr = O.Problem(p, cells, quad, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, cell_block=block, dof_numbering=numbering)
+    assert mesh.cell_block_offsets is not None and int(mesh.cell_block_offsets[-1]) == mesh.n_cells
+    perm = mesh.global_ids.astype(np.int64)            # local index -> lexicographic id of the oracle
+    assert {tuple(perm[r]) for r in mesh.l2g.astype(np.int64)} == {tuple(r) for r in pr.mesh.l2g.astype(np.int64)}
+    op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
+    op.mf_data.set_apply_variant(50)
+    s = O.deterministic_src(mesh.n_owned, seed=13)      # lexicographic
+    src = dev(s[perm])
+    d1 = op.initialize_dof_vector()
+    d1.fill_(float("nan"))                              # overwrite mode must define every entry
+    op.vmult(d1, src)
+    ref = pr.vmult(s)[perm]
+    assert rel(d1.cpu().numpy(), ref) < TOL_OP
+    d2 = op.initialize_dof_vector()
+    d2.fill_(float("nan"))
+    op.vmult(d2, src)
+    assert torch.equal(d1, d2)                          # no atomics anywhere: bitwise reproducible
+    acc = op.initialize_dof_vector()
+    op.mf_data.cell_loop(op.coef, src, acc)
+    op.mf_data.cell_loop(op.coef, src, acc)             # accumulate mode
+    ref2 = 2 * O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]
+    assert rel(acc.cpu().numpy(), ref2) < TOL_OP
+    # the other kernels on the permuted numbering
+    for v in (0, 10):
+        op.mf_data.set_apply_variant(v)
+        d3 = op.initialize_dof_vector()
+        op.vmult(d3, src)
+        assert rel(d3.cpu().numpy(), ref) < TOL_OP
+    op.mf_data.set_apply_variant(50)
+    # CG through the block kernel
+    b = op.assemble_rhs()
+    assert rel(b.cpu().numpy(), pr.rhs()[perm]) < 1e-13
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 6)
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(6, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
 
 
 def test_vmult_dirichlet_and_zero_out_flag():

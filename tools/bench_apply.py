@@ -17,9 +17,12 @@ ap.add_argument("--quadrature", default="gauss")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--deform", type=float, default=0.0)
+ap.add_argument("--cell-block", type=int, nargs=3, default=[0, 0, 0])
+ap.add_argument("--numbering", type=int, default=0)
+ap.add_argument("--overwrite", action="store_true", help="time vmult with zero_dst=1 instead of the accumulating cell loop")
 a = ap.parse_args()
 p = a.degree
-mesh = pkg.BrickMesh(p, a.cells, h=1.0 / a.cells[0], deform_amp=a.deform)
+mesh = pkg.BrickMesh(p, a.cells, h=1.0 / a.cells[0], deform_amp=a.deform, cell_block=a.cell_block, dof_numbering=a.numbering)
 quad = pkg.QUAD_GAUSS if a.quadrature == "gauss" else pkg.QUAD_GLL
 op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
 mf = op.mf_data
@@ -36,7 +39,10 @@ for rnd in range(a.rounds + 1):
         torch.cuda.synchronize()
         ev[0].record()
         for _ in range(a.reps):
-            mf.cell_loop(op.coef, src, dst)
+            if a.overwrite:
+                op.vmult(dst, src)
+            else:
+                mf.cell_loop(op.coef, src, dst)
         ev[1].record()
         torch.cuda.synchronize()
         if rnd:
