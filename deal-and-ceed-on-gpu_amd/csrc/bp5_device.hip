@@ -973,13 +973,13 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
     KERNEL_CHECK();
     int it = 1;
     for (; it <= prm->max_iter; ++it) {
-      if (it == 1) hipLaunchKernelGGL(cgm_update_kernel<0>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-      else if (it % 2 == 0) hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-      else hipLaunchKernelGGL(cgm_update_kernel<2>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      if (it == 1) hipLaunchKernelGGL(cgm_update_kernel<0>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      else if (it % 2 == 0) hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      else hipLaunchKernelGGL(cgm_update_kernel<2>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
       KERNEL_CHECK();
       BP5_TRY(solver_vmult(mf, coef, d, h, true, prof)); // overwrite mode: v needs no zeroing (the reference zeroes it in update_a*)
-      hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid1), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
-      hipLaunchKernelGGL(finalize_kernel<7>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_R0, mf->d_st);
+      hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
+      hipLaunchKernelGGL(finalize_kernel<7>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
       hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
@@ -990,7 +990,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
       }
     }
     // epilogue x update (solver.h:510-526) runs inside the next update kernel
-    hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid1), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+    hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
     hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
   }

@@ -1300,6 +1300,24 @@ __global__ void __launch_bounds__(VB) cg_direction_kernel(double *d, const doubl
 // If the solve finished in the previous iteration with an x update pending, the kernel performs
 // the epilogue (solver.h:510-526) instead: odd it: x += alpha p ; even it: update_c (:315-336).
 template <int MODE>
+__device__ __forceinline__ void cgm_update_one(double &p, double &r, const double v, double &x, const double di, const bool done,
+                                               const bool epi_odd, const double alpha, const double beta, const double aob)
+{
+  if (done) {
+    if (epi_odd) x += alpha * p;
+    else x += (alpha + aob) * p + aob * di * r;
+    return;
+  }
+  if (MODE == 0) {
+    p = -di * r;
+  } else {
+    if (MODE == 2) x += (alpha + aob) * p + aob * di * r;
+    const double rn = r + alpha * v;
+    r = rn;
+    p = beta * p - di * rn;
+  }
+}
+template <int MODE>
 __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, const double *v, double *x, const double *diag, size_t n,
                                                        const double *sc, const int *st)
 {
@@ -1308,22 +1326,26 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, co
   const double alpha = sc[SC_ALPHA], beta = sc[SC_BETA];
   const double aob = (MODE == 2 || done) ? sc[SC_ALPHA_OLD] / sc[SC_BETA_OLD] : 0.0;
   const bool epi_odd = done && (st[ST_ITER] & 1);
-  const size_t stride = (size_t)gridDim.x * VB;
-  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += stride) {
-    const double di = diag ? diag[i] : 1.0;
-    if (done) {
-      if (epi_odd) x[i] += alpha * p[i];
-      else x[i] += (alpha + aob) * p[i] + aob * di * r[i];
-      continue;
-    }
-    if (MODE == 0) {
-      p[i] = -di * r[i];
+  const bool touch_x = done || MODE == 2, touch_rp = !done;
+  const size_t stride = (size_t)gridDim.x * VB * 2;
+  for (size_t i = ((size_t)blockIdx.x * VB + threadIdx.x) * 2; i < n; i += stride) {
+    if (i + 1 < n) {
+      double2 pv = *reinterpret_cast<double2 *>(p + i), rv = *reinterpret_cast<double2 *>(r + i);
+      double2 vv = (MODE != 0 && !done) ? *reinterpret_cast<const double2 *>(v + i) : double2{0, 0};
+      double2 xv = touch_x ? *reinterpret_cast<double2 *>(x + i) : double2{0, 0};
+      const double d0 = diag ? diag[i] : 1.0, d1 = diag ? diag[i + 1] : 1.0;
+      cgm_update_one<MODE>(pv.x, rv.x, vv.x, xv.x, d0, done, epi_odd, alpha, beta, aob);
+      cgm_update_one<MODE>(pv.y, rv.y, vv.y, xv.y, d1, done, epi_odd, alpha, beta, aob);
+      if (touch_rp) {
+        *reinterpret_cast<double2 *>(p + i) = pv;
+        if (MODE != 0) *reinterpret_cast<double2 *>(r + i) = rv;
+      }
+      if (touch_x) *reinterpret_cast<double2 *>(x + i) = xv;
     } else {
-      const double r_old = r[i], p_old = p[i];
-      if (MODE == 2) x[i] += (alpha + aob) * p_old + aob * di * r_old;
-      const double rn = r_old + alpha * v[i];
-      r[i] = rn;
-      p[i] = beta * p_old - di * rn;
+      double pi = p[i], ri = r[i], xi = x[i];
+      cgm_update_one<MODE>(pi, ri, (MODE != 0 && !done) ? v[i] : 0.0, xi, diag ? diag[i] : 1.0, done, epi_odd, alpha, beta, aob);
+      if (touch_rp) { p[i] = pi; if (MODE != 0) r[i] = ri; }
+      if (touch_x) x[i] = xi;
     }
   }
 }
@@ -1333,11 +1355,19 @@ __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const dou
 {
   if (st[ST_DONE]) return;
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  const size_t stride = (size_t)gridDim.x * VB;
-  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += stride) {
-    const double pi = p[i], ri = r[i], vi = v[i], di = diag ? diag[i] : 1.0;
+  auto one = [&](double pi, double ri, double vi, double di) {
     acc[0] += pi * vi; acc[1] += vi * vi; acc[2] += ri * vi; acc[3] += ri * ri;
     acc[4] += ri * di * vi; acc[5] += vi * di * vi; acc[6] += ri * di * ri;
+  };
+  const size_t stride = (size_t)gridDim.x * VB * 2;
+  for (size_t i = ((size_t)blockIdx.x * VB + threadIdx.x) * 2; i < n; i += stride) {
+    if (i + 1 < n) {
+      const double2 pv = *reinterpret_cast<const double2 *>(p + i), rv = *reinterpret_cast<const double2 *>(r + i),
+                    vv = *reinterpret_cast<const double2 *>(v + i);
+      one(pv.x, rv.x, vv.x, diag ? diag[i] : 1.0);
+      one(pv.y, rv.y, vv.y, diag ? diag[i + 1] : 1.0);
+    } else
+      one(p[i], r[i], v[i], diag ? diag[i] : 1.0);
   }
   block_reduce_store<7>(acc, partials);
 }
