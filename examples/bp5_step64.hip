@@ -1,0 +1,351 @@
+// C++ host program written against the deal.II-shaped facade (include/bp5_dealii_facade.hpp):
+// the BP5 Poisson operator and the step-64 Helmholtz operator as user device functors, the fused
+// library path, and the two CG solvers -- the host-side shape of the reference's
+// bp5/step-64.cu (PoissonProblem) and step-64/step-64.cu (HelmholtzProblem).
+//
+//   bp5_step64 check <degree> <nx> <ny> <nz> <deform> <prefix>   functor path vs fused path; dumps vectors
+//   bp5_step64 bench <degree> <n> <iterations> <repetitions>     prints pcg-standard / pcg-merged / vmult lines
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bp5_dealii_facade.hpp"
+
+using namespace bp5::dealii_facade;
+
+// ---- merged-metric functor (role of JacobianFunctor, bp5/step-64.cu:60-114)
+template <int dim, int fe_degree>
+class MetricFunctor {
+public:
+  MetricFunctor(double *c, unsigned int nc) : coef(c), n_cells(nc) {}
+  static const unsigned int n_dofs_1d = fe_degree + 1;
+  static const unsigned int n_q_points = Utilities::pow(n_dofs_1d, dim);
+  __device__ void operator()(const unsigned int cell, const typename CUDAWrappers::MatrixFree<dim, double>::Data *gpu_data)
+  {
+    const unsigned int q = CUDAWrappers::q_point_id_in_cell<dim>(n_dofs_1d);
+    const size_t plane = (size_t)gpu_data->n_cells * gpu_data->padding_length;
+    const size_t at = (size_t)cell * gpu_data->padding_length + q;
+    double K[dim][dim];
+    for (int d = 0; d < dim; ++d)
+      for (int e = 0; e < dim; ++e) K[d][e] = gpu_data->inv_jacobian[at + plane * (d * dim + e)];
+    const double jxw = gpu_data->JxW[at];
+    const size_t o = q + (size_t)cell * n_q_points, stride = (size_t)n_cells * n_q_points;
+    unsigned int c = 0;
+    for (int d = 0; d < dim; ++d, ++c) coef[o + c * stride] = jxw * (K[d][0] * K[d][0] + K[d][1] * K[d][1] + K[d][2] * K[d][2]);
+    for (int d = 0; d < dim; ++d)
+      for (int e = d + 1; e < dim; ++e, ++c) coef[o + c * stride] = jxw * (K[d][0] * K[e][0] + K[d][1] * K[e][1] + K[d][2] * K[e][2]);
+  }
+
+private:
+  double *coef;
+  const unsigned int n_cells;
+};
+
+// ---- BP5 cell operator through FEEvaluation (role of LocalPoissonOperator, bp5/step-64.cu:118-194).
+// MERGED: read the six planes written by MetricFunctor (WITH the cell offset the reference forgets,
+// SURVEY 0.5); otherwise the unmerged submit_gradient(get_gradient()) path.
+template <int dim, int fe_degree, bool MERGED>
+class LocalPoisson {
+public:
+  LocalPoisson(const double *c, unsigned int nc) : coef(c), n_cells(nc) {}
+  static const unsigned int n_dofs_1d = fe_degree + 1;
+  static const unsigned int n_local_dofs = Utilities::pow(fe_degree + 1, dim);
+  static const unsigned int n_q_points = Utilities::pow(fe_degree + 1, dim);
+  __device__ void operator()(const unsigned int cell, const typename CUDAWrappers::MatrixFree<dim, double>::Data *gpu_data,
+                             CUDAWrappers::SharedData<dim, double> *shared_data, const double *src, double *dst) const
+  {
+    CUDAWrappers::FEEvaluation<dim, fe_degree, fe_degree + 1, 1, double> fe_eval(cell, gpu_data, shared_data);
+    fe_eval.read_dof_values(src);
+    fe_eval.evaluate(false, true);
+    if (MERGED) {
+      const size_t stride = (size_t)n_q_points * n_cells;
+      const unsigned int q = CUDAWrappers::internal::compute_index<dim, fe_degree + 1>();
+      const double *S = coef + (size_t)cell * n_q_points + q;
+      const double a = shared_data->gradients[0][q], b = shared_data->gradients[1][q], c = shared_data->gradients[2][q];
+      shared_data->gradients[0][q] = S[0] * a + S[3 * stride] * b + S[4 * stride] * c;
+      shared_data->gradients[1][q] = S[3 * stride] * a + S[stride] * b + S[5 * stride] * c;
+      shared_data->gradients[2][q] = S[4 * stride] * a + S[5 * stride] * b + S[2 * stride] * c;
+      __syncthreads();
+    } else {
+      fe_eval.submit_gradient(fe_eval.get_gradient());
+    }
+    fe_eval.integrate(false, true);
+    fe_eval.distribute_local_to_global(dst);
+  }
+
+private:
+  const double *coef;
+  const unsigned int n_cells;
+};
+
+// ---- step-64 Helmholtz: (grad v, grad u) + (v, a(x) u), a = 10/(0.05 + 2|x|^2) (step-64/step-64.cu:99-219)
+template <int dim, int fe_degree>
+class VaryingCoefficient {
+public:
+  explicit VaryingCoefficient(double *c) : coef(c) {}
+  static const unsigned int n_dofs_1d = fe_degree + 1;
+  static const unsigned int n_q_points = Utilities::pow(n_dofs_1d, dim);
+  __device__ void operator()(const unsigned int cell, const typename CUDAWrappers::MatrixFree<dim, double>::Data *gpu_data)
+  {
+    const unsigned int pos = CUDAWrappers::local_q_point_id<dim, double>(cell, gpu_data, n_dofs_1d, n_q_points);
+    const auto x = CUDAWrappers::get_quadrature_point<dim, double>(cell, gpu_data, n_dofs_1d);
+    double r2 = 0;
+    for (int d = 0; d < dim; ++d) r2 += x[d] * x[d];
+    coef[pos] = 10.0 / (0.05 + 2.0 * r2);
+  }
+
+private:
+  double *coef;
+};
+template <int dim, int fe_degree>
+class HelmholtzQuad {
+public:
+  explicit __device__ HelmholtzQuad(double c) : coef(c) {}
+  __device__ void operator()(CUDAWrappers::FEEvaluation<dim, fe_degree> *fe_eval, const unsigned int q) const
+  {
+    fe_eval->submit_value(coef * fe_eval->get_value(q), q);
+    fe_eval->submit_gradient(fe_eval->get_gradient(q), q);
+  }
+
+private:
+  double coef;
+};
+template <int dim, int fe_degree>
+class LocalHelmholtz {
+public:
+  explicit LocalHelmholtz(const double *c) : coef(c) {}
+  static const unsigned int n_dofs_1d = fe_degree + 1;
+  static const unsigned int n_local_dofs = Utilities::pow(fe_degree + 1, dim);
+  static const unsigned int n_q_points = Utilities::pow(fe_degree + 1, dim);
+  __device__ void operator()(const unsigned int cell, const typename CUDAWrappers::MatrixFree<dim, double>::Data *gpu_data,
+                             CUDAWrappers::SharedData<dim, double> *shared_data, const double *src, double *dst) const
+  {
+    const unsigned int pos = CUDAWrappers::local_q_point_id<dim, double>(cell, gpu_data, n_dofs_1d, n_q_points);
+    CUDAWrappers::FEEvaluation<dim, fe_degree> fe_eval(cell, gpu_data, shared_data);
+    fe_eval.read_dof_values(src);
+    fe_eval.evaluate(true, true);
+    fe_eval.apply_quad_point_operations(HelmholtzQuad<dim, fe_degree>(coef[pos]));
+    fe_eval.integrate(true, true);
+    fe_eval.distribute_local_to_global(dst);
+  }
+
+private:
+  const double *coef;
+};
+
+// ---- operator wrapper with the reference's public surface (bp5/step-64.cu:198-276)
+template <int dim, int fe_degree>
+class PoissonOperator {
+public:
+  PoissonOperator(const bp5_mesh_view &mv, int quadrature, bool use_functor_path) : functor_path(use_functor_path), do_zero_out(true)
+  {
+    bp5_mf_desc d{};
+    d.dim = dim; d.degree = fe_degree; d.quadrature = quadrature; d.coefficient = BP5_COEF_ONE;
+    d.n_cells = mv.n_cells; d.n_interior_cells = mv.n_interior_cells; d.n_owned = mv.n_owned; d.n_ghost = mv.n_ghost;
+    d.local_to_global_host = mv.local_to_global_host; d.node_coords_host = mv.node_coords_host;
+    d.constrained_host = mv.constrained_host; d.n_constrained = mv.n_constrained;
+    mf_data.reinit(d);
+    n_owned_cells = mv.n_cells;
+    n_local = mv.n_owned + mv.n_ghost;
+    size_t nc;
+    check(bp5_mf_coef_size(mf_data.handle(), &nc));
+    check(bp5_vec_alloc(nc, &coef_fast));
+    check(bp5_mf_compute_merged_metric(mf_data.handle(), coef_fast)); // library layout, fused kernels
+    check(bp5_vec_alloc(nc, &coef_ref));
+    mf_data.evaluate_coefficients(MetricFunctor<dim, fe_degree>(coef_ref, n_owned_cells)); // reference layout, functor path
+  }
+  ~PoissonOperator() { bp5_vec_free(coef_fast); bp5_vec_free(coef_ref); }
+  void vmult(double *dst, const double *src) const
+  {
+    if (!functor_path) { check(bp5_apply(mf_data.handle(), coef_fast, src, dst, do_zero_out)); return; }
+    if (do_zero_out) check(bp5_vec_fill(mf_data.handle(), dst, 0.0, n_local));
+    mf_data.cell_loop(LocalPoisson<dim, fe_degree, true>(coef_ref, n_owned_cells), src, dst);
+    mf_data.copy_constrained_values(src, dst);
+  }
+  void vmult_unmerged(double *dst, const double *src) const
+  {
+    check(bp5_vec_fill(mf_data.handle(), dst, 0.0, n_local));
+    mf_data.cell_loop(LocalPoisson<dim, fe_degree, false>(nullptr, n_owned_cells), src, dst);
+    mf_data.copy_constrained_values(src, dst);
+  }
+  void initialize_dof_vector(double **v) const { mf_data.initialize_dof_vector(v); }
+  bp5_mf *handle() const { return mf_data.handle(); }
+  const double *coef() const { return coef_fast; }
+  const double *coef_reference_layout() const { return coef_ref; }
+  CUDAWrappers::MatrixFree<dim, double> mf_data;
+  bool functor_path;
+
+private:
+  double *coef_fast = nullptr, *coef_ref = nullptr;
+  unsigned int n_owned_cells = 0, n_local = 0;
+
+public:
+  bool do_zero_out;
+};
+
+static std::vector<double> download(const double *d, size_t n)
+{
+  std::vector<double> h(n);
+  check(bp5_copy_d2h(h.data(), d, n * sizeof(double)));
+  return h;
+}
+static double rel_diff(const std::vector<double> &a, const std::vector<double> &b)
+{
+  double num = 0, den = 0;
+  for (size_t i = 0; i < a.size(); ++i) { num += (a[i] - b[i]) * (a[i] - b[i]); den += b[i] * b[i]; }
+  return std::sqrt(num / den);
+}
+static void dump(const std::string &path, const std::vector<double> &v)
+{
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) throw std::runtime_error("cannot write " + path);
+  fwrite(v.data(), sizeof(double), v.size(), f);
+  fclose(f);
+}
+
+template <int fe_degree>
+static int run_check(uint32_t nx, uint32_t ny, uint32_t nz, double deform, const std::string &prefix)
+{
+  constexpr int dim = 3;
+  bp5_mesh_desc md{};
+  md.degree = fe_degree; md.cells[0] = nx; md.cells[1] = ny; md.cells[2] = nz; md.h = 1.0; md.deform_amp = deform; md.rank = 0; md.n_ranks = 1;
+  bp5_mesh *mesh;
+  check(bp5_mesh_create_brick(&md, &mesh));
+  bp5_mesh_view mv;
+  check(bp5_mesh_view_get(mesh, &mv));
+  const size_t n = mv.n_owned;
+  PoissonOperator<dim, fe_degree> fast(mv, BP5_QUAD_GAUSS, false), generic(mv, BP5_QUAD_GAUSS, true);
+  // deterministic source with non-zero boundary values
+  std::vector<double> s(n);
+  uint64_t state = 88172645463325252ull;
+  for (auto &x : s) { state ^= state << 13; state ^= state >> 7; state ^= state << 17; x = (double)(state >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
+  double *src, *d1, *d2, *d3;
+  fast.initialize_dof_vector(&src); fast.initialize_dof_vector(&d1); fast.initialize_dof_vector(&d2); fast.initialize_dof_vector(&d3);
+  check(bp5_copy_h2d(src, s.data(), n * sizeof(double)));
+  fast.vmult(d1, src);
+  generic.vmult(d2, src);
+  generic.vmult_unmerged(d3, src);
+  check(bp5_mf_sync(fast.handle()));
+  check(bp5_mf_sync(generic.handle()));
+  const auto h1 = download(d1, n), h2 = download(d2, n), h3 = download(d3, n);
+  // metric: functor (reference layout) vs library (converted)
+  size_t nc;
+  check(bp5_mf_coef_size(fast.handle(), &nc));
+  double *cref;
+  check(bp5_vec_alloc(nc, &cref));
+  check(bp5_mf_metric_to_reference_layout(fast.handle(), fast.coef(), cref));
+  check(bp5_mf_sync(fast.handle()));
+  const double e_metric = rel_diff(download(generic.coef_reference_layout(), nc), download(cref, nc));
+  // Helmholtz through the functor path
+  double *hcoef, *dh;
+  check(bp5_vec_alloc((size_t)mv.n_cells * Utilities::pow(fe_degree + 1, dim), &hcoef));
+  fast.initialize_dof_vector(&dh);
+  generic.mf_data.evaluate_coefficients(VaryingCoefficient<dim, fe_degree>(hcoef));
+  generic.mf_data.cell_loop(LocalHelmholtz<dim, fe_degree>(hcoef), src, dh);
+  generic.mf_data.copy_constrained_values(src, dh);
+  check(bp5_mf_sync(generic.handle()));
+  // CG through the facade solvers
+  double *b, *x1, *x2;
+  fast.initialize_dof_vector(&b); fast.initialize_dof_vector(&x1); fast.initialize_dof_vector(&x2);
+  check(bp5_assemble_rhs(fast.handle(), b));
+  IterationNumberControl c1(10, 0.0), c2(10, 0.0);
+  SolverCG cg(c1);
+  cg.solve(fast, x1, b, DiagonalMatrix());
+  SolverCGFullMerge cgm(c2);
+  cgm.solve(fast, x2, b, DiagonalMatrix());
+  const double e_cg = rel_diff(download(x2, n), download(x1, n));
+  printf("check p=%d cells=%ux%ux%u dofs=%zu\n", fe_degree, nx, ny, nz, n);
+  printf("functor_vs_fused %.3e\nunmerged_vs_fused %.3e\nmetric_functor_vs_library %.3e\nmerged_vs_plain_cg %.3e iterations %u %u\n",
+         rel_diff(h2, h1), rel_diff(h3, h1), e_metric, e_cg, c1.last_step(), c2.last_step());
+  dump(prefix + "_src.bin", s);
+  dump(prefix + "_poisson.bin", h1);
+  dump(prefix + "_poisson_functor.bin", h2);
+  dump(prefix + "_helmholtz.bin", download(dh, n));
+  dump(prefix + "_cg.bin", download(x1, n));
+  bp5_mesh_destroy(mesh);
+  return 0;
+}
+
+template <int fe_degree>
+static int run_bench(uint32_t ncell, int n_iterations, int n_repetitions)
+{ // measurement protocol of PoissonProblem::solve, bp5/step-64.cu:422-561
+  constexpr int dim = 3;
+  bp5_mesh_desc md{};
+  md.degree = fe_degree; md.cells[0] = md.cells[1] = md.cells[2] = ncell; md.h = 1.0 / ncell; md.n_ranks = 1;
+  bp5_mesh *mesh;
+  check(bp5_mesh_create_brick(&md, &mesh));
+  bp5_mesh_view mv;
+  check(bp5_mesh_view_get(mesh, &mv));
+  PoissonOperator<dim, fe_degree> A(mv, BP5_QUAD_GAUSS, false);
+  double *b, *x;
+  A.initialize_dof_vector(&b); A.initialize_dof_vector(&x);
+  check(bp5_assemble_rhs(A.handle(), b));
+  double bb;
+  check(bp5_vec_dot(A.handle(), b, b, mv.n_owned, &bb));
+  printf("   Number of active cells:       %u\n   Number of degrees of freedom: %llu\n\n", mv.n_cells, (unsigned long long)mv.n_global_dofs);
+  for (int variant = 0; variant < 2; ++variant) {
+    double best = 0;
+    for (int r = 0; r < n_repetitions; ++r) {
+      IterationNumberControl control(n_iterations, 1e-6 * std::sqrt(bb));
+      bp5_cg_result res;
+      if (variant == 0) { SolverCG cg(control); cg.solve(A, x, b, DiagonalMatrix()); res = cg.result; }
+      else { SolverCGFullMerge cg(control); cg.solve(A, x, b, DiagonalMatrix()); res = cg.result; }
+      const double thr = (double)mv.n_global_dofs * control.last_step() / (res.solve_ms * 1e-3);
+      best = std::max(best, thr);
+      double xx;
+      check(bp5_vec_dot(A.handle(), x, x, mv.n_owned, &xx));
+      printf("   Solved in %u iterations with time %g and DoFs/s %g norm %.12g\n", control.last_step(), res.solve_ms * 1e-3, thr, std::sqrt(xx));
+    }
+    printf("%s %llu %g\n\n", variant == 0 ? "pcg-standard" : "pcg-merged", (unsigned long long)mv.n_global_dofs, best);
+  }
+  {
+    double best = 0;
+    bp5_event *e0, *e1;
+    check(bp5_event_create(&e0)); check(bp5_event_create(&e1));
+    for (int r = 0; r < n_repetitions; ++r) {
+      check(bp5_event_record(A.handle(), e0));
+      for (int t = 0; t < n_iterations; ++t) A.vmult(x, b);
+      check(bp5_event_record(A.handle(), e1));
+      double ms;
+      check(bp5_event_elapsed_ms(e0, e1, &ms));
+      const double thr = (double)mv.n_global_dofs * n_iterations / (ms * 1e-3);
+      best = std::max(best, thr);
+      printf("   %d mat-vecs in time %g and DoFs/s %g\n", n_iterations, ms * 1e-3, thr);
+    }
+    printf("vmult %llu %g\n\n", (unsigned long long)mv.n_global_dofs, best);
+    bp5_event_destroy(e0); bp5_event_destroy(e1);
+  }
+  bp5_mesh_destroy(mesh);
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  try {
+    if (argc >= 8 && !strcmp(argv[1], "check")) {
+      const int p = atoi(argv[2]);
+      const uint32_t nx = atoi(argv[3]), ny = atoi(argv[4]), nz = atoi(argv[5]);
+      const double deform = atof(argv[6]);
+      switch (p) {
+        case 2: return run_check<2>(nx, ny, nz, deform, argv[7]);
+        case 3: return run_check<3>(nx, ny, nz, deform, argv[7]);
+        case 4: return run_check<4>(nx, ny, nz, deform, argv[7]);
+      }
+    } else if (argc >= 6 && !strcmp(argv[1], "bench")) {
+      const int p = atoi(argv[2]);
+      switch (p) {
+        case 4: return run_bench<4>(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
+        case 5: return run_bench<5>(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
+      }
+    }
+    fprintf(stderr, "usage: %s check <2|3|4> nx ny nz deform prefix | bench <4|5> n iterations repetitions\n", argv[0]);
+    return 2;
+  } catch (const std::exception &e) {
+    // same shape as the reference's top-level handler, bp5/step-64.cu:735-759
+    fprintf(stderr, "\n----------------------------------------------------\nException on processing:\n%s\nAborting!\n", e.what());
+    return 1;
+  }
+}

@@ -256,6 +256,28 @@ def apply_cells_unmerged(mesh, K, JxW, N, D, src, kappa_q=None):
     return dst
 
 
+def apply_helmholtz_cells(mesh, N, D, w, src, coefficient=kappa_step64):
+    """step-64 Helmholtz cell loop (grad v, grad u) + (v, a(x) u), a = 10/(0.05+2|x|^2)
+    (step-64/step-64.cu:99-118,154-160,201-219): evaluate(true,true); per q-point
+    submit_value(a * u) and submit_gradient(get_gradient()); integrate(true,true)."""
+    n = mesh.n
+    K, JxW, xq = jacobians(mesh, N, D, w)
+    idx = mesh.l2g.astype(np.int64)
+    u = src[idx].reshape(mesh.n_cells, n, n, n)
+    uq = _interp(u, N).reshape(mesh.n_cells, -1)
+    g = np.stack([x.reshape(mesh.n_cells, -1) for x in _grad_ref(u, N, D)], axis=-1)
+    phys = np.einsum("cqde,cqd->cqe", K, g)
+    t = (np.einsum("cqde,cqe->cqd", K, phys) * JxW[..., None]).reshape(mesh.n_cells, n, n, n, 3)
+    tv = (coefficient(xq) * uq * JxW).reshape(mesh.n_cells, n, n, n)
+    y = (np.einsum("ck,bj,ai,...cba->...kji", N, N, N, tv, optimize=True)
+         + np.einsum("ck,bj,ai,...cba->...kji", N, N, D, t[..., 0], optimize=True)
+         + np.einsum("ck,bj,ai,...cba->...kji", N, D, N, t[..., 1], optimize=True)
+         + np.einsum("ck,bj,ai,...cba->...kji", D, N, N, t[..., 2], optimize=True))
+    dst = np.zeros(mesh.n_dofs)
+    np.add.at(dst, idx.ravel(), y.reshape(-1))
+    return dst
+
+
 def vmult(mesh, coef, N, D, src):
     """PoissonOperator::vmult (bp5/step-64.cu:263-276): cell loop on unmodified src, then
     dst[c] = src[c] on Dirichlet DoFs."""

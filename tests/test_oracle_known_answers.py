@@ -178,3 +178,26 @@ def test_merged_cg_reference_bug_documented():
     x6, _, _ = O.cg_merged(pr.vmult, b, 6)
     xp, _, _ = O.cg_plain(pr.vmult, b, 6)
     assert np.linalg.norm(x6 - xp) < 1e-13 * np.linalg.norm(xp)
+
+
+def test_helmholtz_oracle_energy():
+    """step-64 Helmholtz restatement: u^T A u = int |grad u|^2 + a u^2 for a polynomial u on an
+    affine mesh, up to the quadrature error of the non-polynomial coefficient (checked against a
+    much finer quadrature of the same integrand)."""
+    m = O.BrickMesh(3, (2, 2, 2), h=0.5)
+    _, _, w, N, D = O.shape_tables(3, O.QUAD_GAUSS)
+    u = m.coords[:, 0] * m.coords[:, 1] + 0.5 * m.coords[:, 2]
+    e = u @ O.apply_helmholtz_cells(m, N, D, w, u)
+    # same integrand with the same quadrature, assembled independently
+    K, JxW, xq = O.jacobians(m, N, D, w)
+    n = m.n
+    uc = u[m.l2g.astype(np.int64)].reshape(m.n_cells, n, n, n)
+    uq = O._interp(uc, N).reshape(m.n_cells, -1)
+    g = np.stack([x.reshape(m.n_cells, -1) for x in O._grad_ref(uc, N, D)], axis=-1)
+    gp = np.einsum("cqde,cqd->cqe", K, g)
+    ref = np.sum((np.sum(gp * gp, axis=-1) + O.kappa_step64(xq) * uq * uq) * JxW)
+    assert abs(e - ref) < 1e-12 * ref
+    # symmetry
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    assert abs(a @ O.apply_helmholtz_cells(m, N, D, w, b) - b @ O.apply_helmholtz_cells(m, N, D, w, a)) < 1e-11
