@@ -65,7 +65,7 @@ struct bp5_mf {
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
-  double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr;
+  double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr, *d_evec = nullptr;
   double *h_sc = nullptr; // pinned
   int *h_st = nullptr;    // pinned
   std::vector<hipEvent_t> ev_pool;
@@ -198,7 +198,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_g, mf->ws_d, mf->ws_h};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_g, mf->ws_d, mf->ws_h, mf->d_evec};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
@@ -457,7 +457,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
 }
 
 // overwrite == true: dst need not be zeroed by the caller, the launch defines every entry
-template <int P, bool COLL, int TW, int LPC, bool PF>
+template <int P, bool COLL, int TW, int LPC, bool PF, int OPT = 0>
 static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
 {
   constexpr int n = P + 1;
@@ -480,12 +480,12 @@ static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
   const bool whole = (c0 == 0 && c1 == mf->n_cells);
   if (!whole || mf->force_atomic_scatter) {
     if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-    hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_ATOMIC>), grid, block, lds, mf->stream, a, tp, sh);
+    hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_ATOMIC, OPT>), grid, block, lds, mf->stream, a, tp, sh);
   } else {
     const bool set = overwrite && dp->covers_all;
     if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-    if (set) hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_SET>), grid, block, lds, mf->stream, a, tp, sh);
-    else hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_ADD>), grid, block, lds, mf->stream, a, tp, sh);
+    if (set) hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_SET, OPT>), grid, block, lds, mf->stream, a, tp, sh);
+    else hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_ADD, OPT>), grid, block, lds, mf->stream, a, tp, sh);
     KERNEL_CHECK();
     return launch_combine(mf, dp, dst, set);
   }
@@ -515,10 +515,15 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
   const bool coll = mf->quadrature == BP5_QUAD_GLL;
   // variants >= 100: the team kernel of (variant - 100) with the global-atomic scatter (A/B tests)
   mf->force_atomic_scatter = mf->apply_variant >= 100;
-  switch (mf->degree * 100 + mf->apply_variant % 100) {
+  int variant = mf->apply_variant % 100;
+  // library defaults from the degree sweep (profiles/r1): x-row team kernel for p = 1 and 3
+  if (mf->apply_variant == 0 && (mf->degree == 1 || mf->degree == 3)) variant = 10;
+  switch (mf->degree * 100 + variant) {
     APPLY_CASE(1, 0, 1, 4, 4, true);
+    APPLY_CASE(1, 1, 1, 4, 4, true);
     APPLY_CASE(2, 0, 1, 9, 4, true);
     APPLY_CASE(3, 0, 1, 16, 4, true);
+    APPLY_CASE(3, 1, 1, 16, 4, true);
     APPLY_CASE(4, 0, 4, 25, 1, true);
     APPLY_CASE(4, 6, 1, 25, 4, true);
     APPLY_CASE(4, 1, 1, 32, 4, true);
@@ -535,6 +540,10 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     APPLY_CASE(8, 1, 2, 81, 1, false);
     // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
 #define ABL_CASE(M) case 400 + 20 + (M): return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
+    case 480: return launch_apply_t<4, false, 4, 25, 1, true, 64>(mf, coef, src, dst, c0, c1);
+    case 481: { // E-vector stores need a big scratch target
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 128>(mf, coef, src, mf->d_evec, c0, c1); }
     ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(5); ABL_CASE(7); ABL_CASE(8); ABL_CASE(9); ABL_CASE(15); ABL_CASE(14); ABL_CASE(13); ABL_CASE(11);
     // block-assembled kernel (compact cell blocks, LDS accumulator, no atomics), variants 50+;
     // a partial cell range cannot use the owner scatter and takes the atomic team kernel instead
@@ -575,6 +584,8 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     TEAM_CASE(4, 11, 8, 25, true);
     TEAM_CASE(4, 12, 4, 25, false);
     TEAM_CASE(4, 13, 2, 25, true);
+    case 414: return coll ? launch_team_t<4, true, 4, 25, true, 32>(mf, coef, src, dst, c0, c1, overwrite)
+                          : launch_team_t<4, false, 4, 25, true, 32>(mf, coef, src, dst, c0, c1, overwrite);
     TEAM_CASE(5, 10, 4, 36, true);
     TEAM_CASE(6, 10, 4, 49, false);
     TEAM_CASE(7, 10, 4, 64, false);

@@ -313,6 +313,16 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
 #pragma unroll
     for (int k = 0; k < n; ++k) acc += y[k];
     if (acc == 1.2345e300) a.dst[idx[0]] = acc; // keeps y live, never taken
+  } else if constexpr (ABL & 64) { // timing only: plain scattered stores instead of atomics
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) a.dst[idx[k]] = y[k];
+    }
+  } else if constexpr (ABL & 128) { // timing only: contiguous E-vector stores (a.dst must hold n_cells*n^3 doubles)
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) a.dst[cell * n3 + k * n2 + abm] = y[k];
+    }
   } else if (active) {
 #pragma unroll
     for (int k = 0; k < n; ++k) atomic_add_f64(a.dst + idx[k], y[k]);
@@ -404,7 +414,14 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 #pragma unroll
   for (int k = 0; k < n; ++k) ps[k] = pos_c[k * n2];
   double u[n];
-  if constexpr (ABL & 4) {
+  if constexpr (ABL & 32) { // direct gather through local_to_global (L2-served re-reads), no LDS staging
+    const uint32_t *l2g_c = a.l2g + cell * n3 + abm;
+    uint32_t idx[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) idx[k] = l2g_c[k * n2];
+#pragma unroll
+    for (int k = 0; k < n; ++k) u[k] = a.src[idx[k]];
+  } else if constexpr (ABL & 4) {
 #pragma unroll
     for (int k = 0; k < n; ++k) u[k] = 1e-9 * (ps[k] + gidx[k % MAXU]);
   } else {
