@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--deform", type=float, default=0.0)
     ap.add_argument("--variant", choices=["merged", "plain"], default="merged")
     ap.add_argument("--apply-variant", type=int, default=0)
+    ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6",
+                    help="merged6: the reference's six stored planes per q-point (G=6, default); affine: per-cell metric + one scalar plane (G=1), affine meshes only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -86,7 +88,9 @@ def main():
     km = pkg.COEF_STEP64 if args.coefficient == "step64" else pkg.COEF_ONE
 
     mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world)
-    op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm)
+    G = 6 if args.geometry == "merged6" else 1
+    op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
+                             geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
     op.mf_data.set_apply_variant(args.apply_variant)
     b = op.assemble_rhs()
     x = op.initialize_dof_vector()
@@ -121,8 +125,8 @@ def main():
 
     if rank == 0:
         n_cells_local, n_dofs_local = mesh.n_cells, mesh.n_owned
-        B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local)
-        B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, operator_only=True)
+        B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
+        B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
         achieved = B_op * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
         out = {
@@ -132,7 +136,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
-                                   f"CG={args.variant} (identity preconditioner), G=6 I=1",
+                                   f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world}"},
             "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
                             "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS},

@@ -13,6 +13,7 @@ _LIB = None
 QUAD_GAUSS, QUAD_GLL = 0, 1
 COEF_ONE, COEF_STEP64 = 0, 1
 CG_PLAIN, CG_MERGED = 0, 1
+GEOM_MERGED6, GEOM_AFFINE = 0, 1
 UNIQUE_ID_BYTES = 128
 
 
@@ -117,6 +118,7 @@ def lib():
         "bp5_mf_coef_size": (i32, [vp, C.POINTER(sz)]),
         "bp5_mf_compute_merged_metric": (i32, [vp, vp]),
         "bp5_mf_metric_to_reference_layout": (i32, [vp, vp, vp]),
+        "bp5_mf_set_geometry_mode": (i32, [vp, i32]),
         "bp5_mf_get_data": (i32, [vp, i32, C.POINTER(MFData)]),
         "bp5_apply": (i32, [vp, vp, vp, vp, i32]),
         "bp5_apply_cells": (i32, [vp, vp, vp, vp, u32, u32]),

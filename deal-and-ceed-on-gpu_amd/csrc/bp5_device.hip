@@ -45,7 +45,8 @@ struct bp5_event {
 struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
-  int apply_variant = 0, n_cus = 0;
+  int apply_variant = 0, n_cus = 0, geometry_mode = 0;
+  double *d_scalar_plane = nullptr, *d_gcell = nullptr;
   bool force_atomic_scatter = false;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -198,7 +199,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_g, mf->ws_d, mf->ws_h, mf->d_evec};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_g, mf->ws_d, mf->ws_h, mf->d_evec, mf->d_scalar_plane, mf->d_gcell};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
@@ -260,6 +261,38 @@ static int launch_geometry(bp5_mf *mf, GeomOut o)
     case 9: return fn<9>(__VA_ARGS__);                                                                             \
   }                                                                                                                \
   return fail(BP5_ERR_INVALID, "unsupported degree")
+
+static int geometry_affine(bp5_mf *mf, GeomOut o) { DISPATCH_N(launch_geometry, mf, o); }
+extern "C" int bp5_mf_set_geometry_mode(bp5_mf *mf, int mode)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  if (mode != BP5_GEOM_MERGED6 && mode != BP5_GEOM_AFFINE) return fail(BP5_ERR_INVALID, "unknown geometry mode");
+  HIP_TRY(hipSetDevice(mf->device));
+  if (mode == BP5_GEOM_AFFINE && !mf->d_scalar_plane) {
+    double *sp = nullptr, *gc = nullptr, *dev = nullptr;
+    const size_t nq = (size_t)mf->n_cells * mf->n3;
+    HIP_TRY(hipMalloc((void **)&sp, std::max<size_t>(nq, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&gc, std::max<size_t>(6 * (size_t)mf->n_cells, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dev, std::max<size_t>(mf->n_cells, 1) * sizeof(double)));
+    GeomOut o{};
+    o.scalar = sp; o.gcell = gc; o.deviation = dev; o.n_cells = mf->n_cells;
+    int st = geometry_affine(mf, o);
+    std::vector<double> h(mf->n_cells);
+    if (st == BP5_OK && hipMemcpyAsync(h.data(), dev, mf->n_cells * sizeof(double), hipMemcpyDeviceToHost, mf->stream) != hipSuccess) st = BP5_ERR_HIP;
+    if (st == BP5_OK && hipStreamSynchronize(mf->stream) != hipSuccess) st = BP5_ERR_HIP;
+    hipFree(dev);
+    double worst = 0.0;
+    for (double v : h) worst = std::max(worst, v);
+    if (st != BP5_OK || !(worst <= 1e-10)) { // rounding noise of the Jacobian is ~eps*|x|/h; real curvature is orders larger
+      hipFree(sp); hipFree(gc);
+      if (st != BP5_OK) return fail(st, "affine geometry setup failed");
+      return fail(BP5_ERR_UNSUPPORTED, "mesh is not affine (K K^T varies inside a cell): use BP5_GEOM_MERGED6");
+    }
+    mf->d_scalar_plane = sp; mf->d_gcell = gc;
+  }
+  mf->geometry_mode = mode;
+  return BP5_OK;
+}
 
 extern "C" int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef)
 {
@@ -337,6 +370,7 @@ static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = c0; a.cell_end = c1;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   a.n_teams = (c1 - c0 + CPT - 1) / CPT;
   const uint32_t nblk = (a.n_teams + TPB - 1) / TPB;
   a.teams_per_xcd = (nblk + 7) / 8;
@@ -436,6 +470,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   ShapeArg<n> sh;
   memcpy(sh.N, mf->tab.N, sizeof(sh.N));
   memcpy(sh.D, mf->tab.D, sizeof(sh.D));
@@ -452,7 +487,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
   }
   KERNEL_CHECK();
-  if (ABL) return BP5_OK;
+  if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass
   return launch_combine(mf, dp, dst, set);
 }
 
@@ -470,6 +505,7 @@ static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = c0; a.cell_end = c1;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   a.n_teams = (c1 + CPT - 1) / CPT - c0 / CPT;
   a.teams_per_xcd = (a.n_teams + 7) / 8;
   ShapeArg<n> sh;
@@ -506,8 +542,42 @@ static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
                 : launch_apply_t<P, false, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)
 
 // overwrite: the launch must leave dst = A src (no prior zeroing by the caller); otherwise dst += A src
+template <int P>
+static int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0, uint32_t c1)
+{ // TW = 4 teams when n^2 lanes per cell pack well into 256 threads, as for the 6-plane default
+  constexpr int n2 = (P + 1) * (P + 1);
+  constexpr int LPC = n2;
+  constexpr bool PF = true;
+  return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<P, true, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1)
+                                        : launch_apply_t<P, false, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1);
+}
 static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite = false)
 {
+  if (mf->geometry_mode == BP5_GEOM_AFFINE && c1 > c0) {
+    const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
+    const bool whole = c0 == 0 && c1 == mf->n_cells;
+    if (mf->degree == 4 && mf->apply_variant % 100 == 10) {
+      mf->force_atomic_scatter = mf->apply_variant >= 100;
+      return coll_ ? launch_team_t<4, true, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite)
+                   : launch_team_t<4, false, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite);
+    }
+    if (mf->degree == 4 && whole && (mf->apply_variant == 50 || mf->apply_variant == 51))
+      return mf->apply_variant == 50 ? (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                              : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
+                                     : (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                              : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    switch (mf->degree) {
+      case 1: return launch_affine<1>(mf, src, dst, c0, c1);
+      case 2: return launch_affine<2>(mf, src, dst, c0, c1);
+      case 3: return launch_affine<3>(mf, src, dst, c0, c1);
+      case 4: return launch_affine<4>(mf, src, dst, c0, c1);
+      case 5: return launch_affine<5>(mf, src, dst, c0, c1);
+      case 6: return launch_affine<6>(mf, src, dst, c0, c1);
+      case 7: return launch_affine<7>(mf, src, dst, c0, c1);
+      case 8: return launch_affine<8>(mf, src, dst, c0, c1);
+    }
+  }
   if (c1 <= c0) {
     if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     return BP5_OK;
@@ -540,6 +610,10 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     APPLY_CASE(8, 1, 2, 81, 1, false);
     // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
 #define ABL_CASE(M) case 400 + 20 + (M): return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
+    case 407: return coll ? launch_apply_t<4, true, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1);
+    case 408: return coll ? launch_apply_t<4, true, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
+    case 409: return coll ? launch_apply_t<4, true, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
+    case 482: return launch_apply_t<4, false, 4, 25, 1, true, 257>(mf, coef, src, dst, c0, c1);
     case 480: return launch_apply_t<4, false, 4, 25, 1, true, 64>(mf, coef, src, dst, c0, c1);
     case 481: { // E-vector stores need a big scratch target
       if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
@@ -596,7 +670,7 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
 
 extern "C" int bp5_apply_cells(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
 {
-  if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
   if (c1 > mf->n_cells || c0 > c1) return fail(BP5_ERR_INVALID, "cell range out of bounds");
   if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
   HIP_TRY(hipSetDevice(mf->device));
@@ -622,7 +696,7 @@ extern "C" int bp5_set_constrained(bp5_mf *mf, double value, double *dst)
 }
 extern "C" int bp5_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, int zero_dst)
 {
-  if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
   if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
   HIP_TRY(hipSetDevice(mf->device));
   BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero_dst != 0));
@@ -923,7 +997,7 @@ static int poll_state(bp5_mf *mf)
 extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, const double *b, double *x, const bp5_cg_params *prm,
                             bp5_cg_result *res)
 {
-  if (!mf || !coef || !b || !x || !prm || !res) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !b || !x || !prm || !res) return fail(BP5_ERR_INVALID, "null argument");
   if (prm->max_iter < 0) return fail(BP5_ERR_INVALID, "max_iter < 0");
   if (prm->variant != BP5_CG_PLAIN && prm->variant != BP5_CG_MERGED) return fail(BP5_ERR_INVALID, "unknown CG variant");
   if (!aligned16(b) || !aligned16(x) || (diag && !aligned16(diag))) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");

@@ -41,6 +41,8 @@ struct ApplyArgs {
   uint32_t cell_begin, cell_end;
   uint32_t n_teams;      // teams needed for the range
   uint32_t teams_per_xcd;
+  const double *gcell;   // affine mode: [6][n_cells] per-cell K K^T (planes 00,11,22,01,02,12); coef = 1 scalar plane
+  uint32_t n_cells_total;
 };
 
 // In-register n x n mat-vec with wave-uniform matrix entries.  The 1-D tables are symmetric
@@ -110,8 +112,9 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v)
 // TPB teams per block (TW > 1 requires TPB == 1), PF: prefetch all six planes before evaluate
 // ABL (timing-only ablation builds, wrong results): bit0 skip the scatter atomics, bit1 skip the
 // metric loads, bit2 skip the src gather, bit3 skip the contractions
+// ABL bit 512: ask the compiler for 4 waves per SIMD (<= 128 VGPRs)
 template <int P, bool COLL, int TW, int LPC, int TPB, bool PF, int ABL = 0>
-__global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) apply_pencil_kernel(ApplyArgs a, ShapeArg<P + 1> sh)
 {
   constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
   constexpr int TEAM = 64 * TW;
@@ -144,18 +147,27 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
   double u[n];
   const uint32_t *l2g_c = a.l2g + cell * n3 + abm;
 #pragma unroll
-  for (int k = 0; k < n; ++k) idx[k] = l2g_c[k * n2];
+  for (int k = 0; k < n; ++k) idx[k] = (ABL & 256) ? __builtin_nontemporal_load(l2g_c + k * n2) : l2g_c[k * n2];
 #pragma unroll
   for (int k = 0; k < n; ++k) u[k] = (ABL & 4) ? 1e-9 * idx[k] : a.src[idx[k]];
 
   // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
   const double *cf = a.coef + cell * n3 + abm;
-  double S[PF ? 6 : 1][n];
-  if constexpr (PF) {
+  constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
+  double S[(PF && !AFFINE) ? 6 : 1][n];
+  double Gc[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (AFFINE) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) S[0][i] = cf[i * n2];
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
+  } else if constexpr (PF) {
 #pragma unroll
     for (int pl = 0; pl < 6; ++pl)
 #pragma unroll
-      for (int i = 0; i < n; ++i) S[pl][i] = (ABL & 2) ? 1.0 + pl + i + 1e-3 * abm : cf[pl * a.plane_stride + i * n2];
+      for (int i = 0; i < n; ++i)
+        S[pl][i] = (ABL & 2) ? 1.0 + pl + i + 1e-3 * abm
+                             : (ABL & 256) ? __builtin_nontemporal_load(cf + pl * a.plane_stride + i * n2) : cf[pl * a.plane_stride + i * n2];
   }
 
   double g0[n], g1[n], g2[n];
@@ -229,7 +241,10 @@ __global__ void __launch_bounds__(64 * TW * TPB) apply_pencil_kernel(ApplyArgs a
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     double s00, s11, s22, s01, s02, s12;
-    if constexpr (PF) {
+    if constexpr (AFFINE) {
+      const double sc = S[0][i];
+      s00 = sc * Gc[0]; s11 = sc * Gc[1]; s22 = sc * Gc[2]; s01 = sc * Gc[3]; s02 = sc * Gc[4]; s12 = sc * Gc[5];
+    } else if constexpr (PF) {
       s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
     } else {
       s00 = cf[0 * a.plane_stride + i * n2];
@@ -402,8 +417,15 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
   const int n_rounds = tp.team_rounds[team];
   // ---- metric planes (issued early; consumed after the evaluate phase)
   const double *cf = a.coef + cell * n3 + abm;
-  double S[PF ? 6 : 1][n];
-  if constexpr (PF) {
+  constexpr bool AFFINE = (ABL & 1024) != 0;
+  double S[(PF && !AFFINE) ? 6 : 1][n];
+  double Gc[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (AFFINE) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) S[0][i] = cf[i * n2];
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
+  } else if constexpr (PF) {
 #pragma unroll
     for (int pl = 0; pl < 6; ++pl)
 #pragma unroll
@@ -491,7 +513,10 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 #pragma unroll
   for (int i = 0; i < n; ++i) {
     double s00, s11, s22, s01, s02, s12;
-    if constexpr (PF) {
+    if constexpr (AFFINE) {
+      const double sc = S[0][i];
+      s00 = sc * Gc[0]; s11 = sc * Gc[1]; s22 = sc * Gc[2]; s01 = sc * Gc[3]; s02 = sc * Gc[4]; s12 = sc * Gc[5];
+    } else if constexpr (PF) {
       s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
     } else {
       s00 = cf[0 * a.plane_stride + i * n2]; s11 = cf[1 * a.plane_stride + i * n2]; s22 = cf[2 * a.plane_stride + i * n2];
@@ -623,11 +648,12 @@ struct BlockPlan {
 };
 
 // register set of one pass (cell ids, positions, gathered values, metric)
-template <int n>
+template <int n, bool AFFINE>
 struct PassRegs {
   uint16_t ps[n];
   double u[n];
-  double S[6][n];
+  double S[AFFINE ? 1 : 6][n]; // affine: one scalar plane ...
+  double Gc[AFFINE ? 6 : 1];   // ... and the cell's constant K K^T
   uint32_t idx[n];
   uint32_t ent; // pass_cell entry
   int round;
@@ -640,7 +666,8 @@ struct BlockPass {
   static constexpr int TEAM = 256;
   static constexpr int CPT = TEAM / LPC;
   using L = LdsLayout<n, LPC>;
-  using R = PassRegs<n>;
+  static constexpr bool AFFINE = (ABL & 1024) != 0;
+  using R = PassRegs<n, AFFINE>;
 
   // issue index / position / metric loads of the cell named by r.ent
   static __device__ __forceinline__ void issue_loads(const ApplyArgs &a, const BlockPlan &bp, R &r, int abm, bool lane_ok, bool exists)
@@ -655,10 +682,17 @@ struct BlockPass {
     for (int k = 0; k < n; ++k) r.ps[k] = pos_c[k * n2];
     r.round = bp.cell_round[cell];
     const double *cf = a.coef + cell * n3 + abm;
+    if constexpr (AFFINE) {
 #pragma unroll
-    for (int pl = 0; pl < 6; ++pl)
+      for (int i = 0; i < n; ++i) r.S[0][i] = cf[i * n2];
 #pragma unroll
-      for (int i = 0; i < n; ++i) r.S[pl][i] = (ABL & 2) ? 1.0 + pl + i : cf[pl * a.plane_stride + i * n2];
+      for (int pl = 0; pl < 6; ++pl) r.Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl)
+#pragma unroll
+        for (int i = 0; i < n; ++i) r.S[pl][i] = (ABL & 2) ? 1.0 + pl + i : cf[pl * a.plane_stride + i * n2];
+    }
   }
   static __device__ __forceinline__ void issue_gather(const ApplyArgs &a, R &r)
   {
@@ -735,9 +769,16 @@ struct BlockPass {
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
-      g0[i] = cur.S[0][i] * x0 + cur.S[3][i] * x1 + cur.S[4][i] * x2;
-      g1[i] = cur.S[3][i] * x0 + cur.S[1][i] * x1 + cur.S[5][i] * x2;
-      g2[i] = cur.S[4][i] * x0 + cur.S[5][i] * x1 + cur.S[2][i] * x2;
+      if constexpr (AFFINE) {
+        const double sc = cur.S[0][i];
+        g0[i] = sc * (cur.Gc[0] * x0 + cur.Gc[3] * x1 + cur.Gc[4] * x2);
+        g1[i] = sc * (cur.Gc[3] * x0 + cur.Gc[1] * x1 + cur.Gc[5] * x2);
+        g2[i] = sc * (cur.Gc[4] * x0 + cur.Gc[5] * x1 + cur.Gc[2] * x2);
+      } else {
+        g0[i] = cur.S[0][i] * x0 + cur.S[3][i] * x1 + cur.S[4][i] * x2;
+        g1[i] = cur.S[3][i] * x0 + cur.S[1][i] * x1 + cur.S[5][i] * x2;
+        g2[i] = cur.S[4][i] * x0 + cur.S[5][i] * x1 + cur.S[2][i] * x2;
+      }
     }
 
     double y[n];
@@ -857,7 +898,7 @@ __global__ void __launch_bounds__(256, 2) apply_block_kernel(ApplyArgs a, BlockP
 
   // two register sets, used alternately (loop unrolled by two): the loads of pass q+1 are issued
   // at the top of pass q and first waited for inside pass q+1
-  PassRegs<n> A, B;
+  PassRegs<n, (ABL & 1024) != 0> A, B;
   A.ent = entry(gp);
   B.ent = entry(gp + 1);
   BP::issue_loads(a, bp, A, abm, lane_ok, true);
@@ -956,6 +997,10 @@ struct GeomOut {
   double *q_points;      // 3 planes of n_cells*pad or NULL
   uint32_t pad;
   uint64_t geo_plane;    // n_cells * pad
+  // affine mode: scalar plane kappa*JxW (permuted layout), per-cell K K^T (6 planes of n_cells), and a
+  // per-cell deviation measure max_q |K K^T(q) - K K^T(q0)| / |K K^T(q0)|
+  double *scalar, *gcell, *deviation;
+  uint32_t n_cells;
 };
 
 __device__ __forceinline__ double kappa_eval(int mode, double x, double y, double z)
@@ -1018,6 +1063,27 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
       c[3 * o.plane_stride] = s * (K[0][0] * K[1][0] + K[0][1] * K[1][1] + K[0][2] * K[1][2]);
       c[4 * o.plane_stride] = s * (K[0][0] * K[2][0] + K[0][1] * K[2][1] + K[0][2] * K[2][2]);
       c[5 * o.plane_stride] = s * (K[1][0] * K[2][0] + K[1][1] * K[2][1] + K[1][2] * K[2][2]);
+    }
+    if (o.scalar) {
+      double Gq[6] = {K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2], K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2],
+                      K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2], K[0][0] * K[1][0] + K[0][1] * K[1][1] + K[0][2] * K[1][2],
+                      K[0][0] * K[2][0] + K[0][1] * K[2][1] + K[0][2] * K[2][2], K[1][0] * K[2][0] + K[1][1] * K[2][1] + K[1][2] * K[2][2]};
+      o.scalar[cell * n3 + (uint64_t)i * n2 + (j + n * k)] = jxw * kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
+      // reference values of the cell: q-point 0
+      for (int c6 = 0; c6 < 6; ++c6) {
+        if (q == 0) { t1[c6] = Gq[c6]; o.gcell[(uint64_t)c6 * o.n_cells + cell] = Gq[c6]; }
+      }
+      __syncthreads();
+      double dev = 0.0, nrm = 0.0;
+      for (int c6 = 0; c6 < 6; ++c6) { dev = fmax(dev, fabs(Gq[c6] - t1[c6])); nrm = fmax(nrm, fabs(t1[c6])); }
+      t2[q] = dev / nrm;
+      __syncthreads();
+      if (q == 0) {
+        double mx = 0.0;
+        for (int m = 0; m < n3; ++m) mx = fmax(mx, t2[m]);
+        o.deviation[cell] = mx;
+      }
+      __syncthreads();
     }
     if (o.inv_jac) {
       const uint64_t at = cell * o.pad + q;

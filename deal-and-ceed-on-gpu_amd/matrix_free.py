@@ -128,6 +128,10 @@ class MatrixFree:
     def synchronize(self):
         _lib.check(_lib.lib().bp5_mf_sync(self.handle))
 
+    def set_geometry_mode(self, mode):
+        """BP5_GEOM_MERGED6 (reference representation, default) or BP5_GEOM_AFFINE (affine meshes)."""
+        _lib.check(_lib.lib().bp5_mf_set_geometry_mode(self.handle, int(mode)))
+
     def set_apply_variant(self, v):
         _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
 
@@ -178,9 +182,14 @@ class MatrixFree:
 class PoissonOperator:
     """== BP5::PoissonOperator<3,fe_degree>, bp5/step-64.cu:198-276."""
 
-    def __init__(self, mesh, quadrature=QUAD_GAUSS, coefficient=COEF_ONE, device=0, comm=None, stream=None):
+    def __init__(self, mesh, quadrature=QUAD_GAUSS, coefficient=COEF_ONE, device=0, comm=None, stream=None, geometry=0):
         self.mf_data = MatrixFree().reinit(mesh, quadrature, coefficient, device, stream, comm)
-        self.coef = self.mf_data.evaluate_coefficients()
+        self.geometry = geometry
+        if geometry == _lib.GEOM_AFFINE:          # per-cell metric + one scalar plane, no 6-plane array at all
+            self.mf_data.set_geometry_mode(geometry)
+            self.coef = None
+        else:
+            self.coef = self.mf_data.evaluate_coefficients()
         self.n_owned_cells = mesh.n_cells
         self.do_zero_out = True                      # bp5/step-64.cu:223,232
         self.distributed = comm is not None and comm.n_ranks > 1

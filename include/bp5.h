@@ -157,6 +157,16 @@ int bp5_mf_coef_size(const bp5_mf *mf, size_t *n_doubles);
  *      coef[c*n_cells*nq + cell*nq + qi*n*n + (qj + n*qk)]
  *    i.e. q-points permuted so that the x index is slowest inside a cell. */
 int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef);
+/* Geometry representation used by bp5_apply / bp5_cg_solve:
+ *   BP5_GEOM_MERGED6  the reference's six stored planes per q-point (G = 6 doubles per q-point), `coef`
+ *                     from bp5_mf_compute_merged_metric -- the default;
+ *   BP5_GEOM_AFFINE   for meshes whose cells are all affine (the reference's meshes always are: congruent
+ *                     cubes, bp5/step-64.cu:656-663): K K^T is constant per cell, so the library keeps six
+ *                     doubles per CELL and one scalar plane kappa*JxW per q-point (G = 1).  Same operator,
+ *                     same results to rounding; the `coef` argument of apply/solve is then ignored.
+ *                     Fails with BP5_ERR_UNSUPPORTED if K K^T varies by more than 1e-10 (relative) inside a cell. */
+enum { BP5_GEOM_MERGED6 = 0, BP5_GEOM_AFFINE = 1 };
+int bp5_mf_set_geometry_mode(bp5_mf *mf, int mode);
 /* permute to the reference layout [c][cell][qi + n(qj + n qk)] (tests / interop) */
 int bp5_mf_metric_to_reference_layout(bp5_mf *mf, const double *coef, double *coef_ref);
 

@@ -184,6 +184,61 @@ def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
         assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
 
 
+@pytest.mark.parametrize("p", range(1, 9))
+@pytest.mark.parametrize("quad", [0, 1])
+def test_affine_geometry_mode(p, quad):
+    """BP5_GEOM_AFFINE (per-cell K K^T + one scalar plane) gives the same operator as the six stored
+    planes on affine meshes (the reference's meshes: cubes), with a variable coefficient."""
+    cells = (3, 3, 2) if p <= 4 else (3, 2, 1)
+    pr = O.Problem(p, cells, quad, h=0.5, kappa=O.kappa_step64)
+    op = pkg.PoissonOperator(pkg.BrickMesh(p, cells, h=0.5), quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE)
+    assert op.coef is None
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=17)
+    dst = op.initialize_dof_vector()
+    op.vmult(dst, dev(s))
+    assert rel(dst.cpu().numpy(), pr.vmult(s)) < TOL_OP
+    b = op.assemble_rhs()
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 8)
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(8, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert rel(x.cpu().numpy(), xr) < TOL_CG
+
+
+@pytest.mark.parametrize("variant,block,numbering", [(10, (0, 0, 0), 0), (110, (0, 0, 0), 0), (50, (4, 4, 4), 1), (51, (4, 4, 2), 0)])
+@pytest.mark.parametrize("quad", [0, 1])
+def test_affine_mode_team_and_block_kernels(variant, block, numbering, quad):
+    p, cells = 4, (8, 5, 4)
+    pr = O.Problem(p, cells, quad, h=0.25, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, h=0.25, cell_block=block, dof_numbering=numbering)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE)
+    op.mf_data.set_apply_variant(variant)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=19)
+    dst = op.initialize_dof_vector()
+    dst.fill_(float("nan"))
+    op.vmult(dst, dev(s[perm]))
+    assert rel(dst.cpu().numpy(), pr.vmult(s)[perm]) < TOL_OP
+    b = op.assemble_rhs()
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 8)
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(8, 0.0)
+    pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+    assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+
+
+def test_affine_mode_rejects_deformed_mesh():
+    mf = pkg.MatrixFree().reinit(pkg.BrickMesh(3, (2, 2, 2), deform_amp=0.03), 0)
+    with pytest.raises(pkg.BP5Error) as e:
+        mf.set_geometry_mode(pkg.GEOM_AFFINE)
+    assert e.value.status == 5                      # BP5_ERR_UNSUPPORTED
+    # sheared but affine cells are fine: handled by the same per-cell 3x3 metric (checked on a
+    # stretched brick: h differs from 1)
+    mf2 = pkg.MatrixFree().reinit(pkg.BrickMesh(2, (2, 3, 2), h=0.37), 1)
+    mf2.set_geometry_mode(pkg.GEOM_AFFINE)
+
+
 def test_vmult_dirichlet_and_zero_out_flag():
     p, cells = 3, (3, 3, 3)
     pr = O.Problem(p, cells, 0, deform_amp=0.05)

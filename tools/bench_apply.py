@@ -19,16 +19,17 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--deform", type=float, default=0.0)
 ap.add_argument("--cell-block", type=int, nargs=3, default=[0, 0, 0])
 ap.add_argument("--numbering", type=int, default=0)
+ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6")
 ap.add_argument("--overwrite", action="store_true", help="time vmult with zero_dst=1 instead of the accumulating cell loop")
 a = ap.parse_args()
 p = a.degree
 mesh = pkg.BrickMesh(p, a.cells, h=1.0 / a.cells[0], deform_amp=a.deform, cell_block=a.cell_block, dof_numbering=a.numbering)
 quad = pkg.QUAD_GAUSS if a.quadrature == "gauss" else pkg.QUAD_GLL
-op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
+op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE if a.geometry == 'affine' else pkg.GEOM_MERGED6)
 mf = op.mf_data
 n = mesh.n_owned
 r = mesh.n_cells * (p + 1) ** 3 / n
-B_op = 16 + 4 * r + 48 * r
+B_op = 16 + 4 * r + (48 if a.geometry == 'merged6' else 8) * r
 src = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
 dst = mf.initialize_dof_vector()
 times = {v: [] for v in a.variants}
