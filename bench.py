@@ -28,6 +28,20 @@ def algorithmic_bytes_per_dof(p, n_cells, n_dofs, G=6, I=1, operator_only=False)
     return 16.0 + I * 4.0 * r + G * 8.0 * r + (0.0 if operator_only else 88.0)
 
 
+def measured_traffic(key):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
+    (profiles/*/traffic.json); None when this workload has not been profiled."""
+    best = None
+    prof = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        f = os.path.join(prof, rnd, "traffic.json")
+        if os.path.exists(f):
+            for e in json.load(open(f))["entries"]:
+                if e["key"] == key:
+                    best = e
+    return best
+
+
 def cpu_baseline(p, quad, cells, iters, deform, km):
     """CPU restatement (oracle/bp5_oracle.c, OpenMP) timed on the host cores: a reported
     baseline ("port"), not deal.II and not the optimisation target."""
@@ -77,8 +91,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
-        comm = pkg.Communicator.from_torch_distributed()
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
 
     p = args.degree
     n1 = {1: 367, 2: 184, 3: 122, 4: 116, 5: 92, 6: 73, 7: 61, 8: 52}[p] if p != 4 else 116
@@ -105,7 +119,8 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up
-    Solver(pkg.IterationNumberControl(max(args.warmup, 1), 0.0)).solve(op, x, b, precond)
+    Solver(pkg.IterationNumberControl(max(args.warmup, 1), 0.0), profile=True).solve(op, x, b, precond)
+    Solver(pkg.IterationNumberControl(args.steps, 0.0), profile=True).solve(op, x, b, precond) if False else None
     barrier()
     ctl = pkg.IterationNumberControl(args.steps, 0.0)
     solver = Solver(ctl, profile=True)
@@ -129,6 +144,8 @@ def main():
         B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
         achieved = B_op * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
+        key = f"p{p}_{args.quadrature}_{cells_per_gpu[0]}x{cells_per_gpu[1]}x{cells_per_gpu[2]}_{args.geometry}_v{args.apply_variant}"
+        tr = measured_traffic(key) if args.deform == 0.0 else None
         out = {
             "metric": "BP5 DoFs/sec per CG iter (p=4, ~1e8 DoFs) + % HBM roofline at 1/2/4/8 GPUs",
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": iters, "warmup": args.warmup,
@@ -140,9 +157,12 @@ def main():
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world}"},
             "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
                             "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS},
-            "roofline": {"bound": "hbm", "kernel": "apply_pencil_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_dof": B_op,
-                         "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches},
+            # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs) / average time between the HIP
+            # events bracketing it inside the timed solve (zero-fill + cell kernel [+ combine pass]); `traffic`: PMC bytes
+            "roofline": {"bound": "hbm", "kernel": tr["kernel"] if tr else "fused BP5 operator (see DESIGN.md 4)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": tr["traffic_bytes"] if tr else None, "algorithmic_bytes": B_op * n_dofs_local,
+                         "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, quad, (40, 40, 40) if p == 4 else (16, 16, 16), 20, args.deform, km)

@@ -24,7 +24,7 @@ class BP5Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libbp5.so")
+    return os.environ.get("BP5_LIB", os.path.join(_HERE, "libbp5.so"))
 
 
 def build(verbose=False):
@@ -148,6 +148,8 @@ def lib():
         "bp5_event_destroy": (i32, [vp]),
     }
     for name, (res, args) in protos.items():
+        if os.environ.get("BP5_LIB") and not hasattr(L, name):
+            continue  # A/B runs against an older build (tools only); the default library must export everything
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
     L._protos = protos

@@ -462,7 +462,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
     mf->n_cus = prop.multiProcessorCount;
   }
-  const int wg_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int wg_per_cu = ((ABL & 2048) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1;
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (dp->n_groups + 7) / 8 * 8) / 8 * 8);
   bp.n_wg = n_wg;
@@ -487,7 +487,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
   }
   KERNEL_CHECK();
-  if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass
+  if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass (1024/2048 are real modes)
   return launch_combine(mf, dp, dst, set);
 }
 
@@ -603,11 +603,24 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     APPLY_CASE(4, 5, 1, 25, 4, false);
     APPLY_CASE(5, 0, 4, 36, 1, true);
     APPLY_CASE(5, 1, 1, 36, 4, true);
-    APPLY_CASE(6, 0, 4, 49, 1, false);
+    APPLY_CASE(5, 2, 4, 36, 1, false);
+    APPLY_CASE(5, 3, 2, 36, 1, true);
+    APPLY_CASE(6, 0, 4, 49, 1, true);   // defaults for p >= 6 from the high-degree sweep: prefetch all planes
+    APPLY_CASE(6, 5, 4, 49, 1, false);
     APPLY_CASE(6, 1, 1, 49, 4, false);
-    APPLY_CASE(7, 0, 1, 64, 4, false);
-    APPLY_CASE(8, 0, 4, 81, 1, false);
+    APPLY_CASE(6, 2, 4, 49, 1, true);
+    APPLY_CASE(6, 3, 1, 49, 1, true);
+    APPLY_CASE(6, 4, 2, 49, 1, false);
+    APPLY_CASE(7, 0, 4, 64, 1, true);
+    APPLY_CASE(7, 5, 1, 64, 4, false);
+    APPLY_CASE(7, 1, 4, 64, 1, false);
+    APPLY_CASE(7, 2, 4, 64, 1, true);
+    APPLY_CASE(7, 3, 1, 64, 1, true);
+    APPLY_CASE(8, 0, 4, 81, 1, true);
+    APPLY_CASE(8, 5, 4, 81, 1, false);
     APPLY_CASE(8, 1, 2, 81, 1, false);
+    APPLY_CASE(8, 2, 4, 81, 1, true);
+    APPLY_CASE(8, 3, 2, 81, 1, true);
     // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
 #define ABL_CASE(M) case 400 + 20 + (M): return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
     case 407: return coll ? launch_apply_t<4, true, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1);
@@ -632,6 +645,12 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     BLOCK_CASE(3, 50, 16, 4, true);
     BLOCK_CASE(4, 50, 25, 4, true);
     BLOCK_CASE(4, 51, 32, 4, true);
+    case 452: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
+    case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 53 needs the whole cell range");
+    case 492: return launch_block_t<4, false, 32, 2049>(mf, coef, src, dst, true);
+    case 496: return launch_block_t<4, false, 32, 2053>(mf, coef, src, dst, true);
     BLOCK_CASE(5, 50, 36, 4, true);
     BLOCK_CASE(6, 50, 49, 4, false);
     BLOCK_CASE(7, 50, 64, 4, false);
@@ -979,6 +998,15 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
 {
   const bool dist = mf->comm && mf->comm->n_ranks > 1;
   if (dist) BP5_TRY(bp5_halo_gather(mf, src));
+  // kernels that accumulate with atomics need a zeroed target: do the fill outside the profiled bracket so
+  // that the bracket times the cell kernel alone (owner-scatter kernels define every entry themselves)
+  const int v = mf->apply_variant % 100;
+  const bool owner_scatter = mf->apply_variant < 100 && (v == 10 || v == 11 || v == 12 || v == 13 || v == 14 || v == 50 || v == 51 || v == 52 || v == 53 ||
+                                                         (mf->apply_variant == 0 && (mf->degree == 1 || mf->degree == 3)));
+  if (zero && !owner_scatter) {
+    HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    zero = false;
+  }
   BP5_TRY(prof.begin());
   BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero));
   BP5_TRY(prof.end());
@@ -1074,10 +1102,13 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
         if (mf->h_st[ST_DONE]) break;
       }
     }
-    // epilogue x update (solver.h:510-526) runs inside the next update kernel
-    hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-    hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
-    KERNEL_CHECK();
+    // epilogue x update (solver.h:510-526) runs inside the next update kernel; with max_iter == 0 no
+    // iteration has been done and nothing is pending
+    if (prm->max_iter > 0) {
+      hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+      KERNEL_CHECK();
+    }
   }
   HIP_TRY(hipEventRecord(ev1, s));
   BP5_TRY(poll_state(mf));

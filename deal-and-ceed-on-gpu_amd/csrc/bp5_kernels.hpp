@@ -667,6 +667,9 @@ struct BlockPass {
   static constexpr int CPT = TEAM / LPC;
   using L = LdsLayout<n, LPC>;
   static constexpr bool AFFINE = (ABL & 1024) != 0;
+  // SINGLE: the metric of a pass is loaded at the top of that pass (as in apply_pencil_kernel) and only the
+  // indices / gathered values are prefetched one pass ahead: ~60 fewer VGPRs -> three workgroups per CU
+  static constexpr bool SINGLE = (ABL & 2048) != 0;
   using R = PassRegs<n, AFFINE>;
 
   // issue index / position / metric loads of the cell named by r.ent
@@ -681,6 +684,11 @@ struct BlockPass {
 #pragma unroll
     for (int k = 0; k < n; ++k) r.ps[k] = pos_c[k * n2];
     r.round = bp.cell_round[cell];
+    if constexpr (!SINGLE) issue_metric(a, r, abm);
+  }
+  static __device__ __forceinline__ void issue_metric(const ApplyArgs &a, R &r, int abm)
+  {
+    const uint64_t cell = r.ent & 0x7fffffffu;
     const double *cf = a.coef + cell * n3 + abm;
     if constexpr (AFFINE) {
 #pragma unroll
@@ -703,8 +711,9 @@ struct BlockPass {
   // one pass: compute with `cur`, keep the loads of `nxt` in flight.  Returns nothing; all
   // block bookkeeping is done by the caller.
   static __device__ __forceinline__ void run(const ApplyArgs &a, const ShapeArg<n> &sh, R &cur, R &nxt, double *T, double *acc, int a_, int b_,
-                                             int n_rounds)
+                                             int n_rounds, int abm)
   {
+    if constexpr (SINGLE) issue_metric(a, cur, abm);
 #define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]
     const bool active = cur.active;
     double(&u)[n] = cur.u;
@@ -860,7 +869,7 @@ struct BlockPass {
 };
 
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;
@@ -951,13 +960,13 @@ __global__ void __launch_bounds__(256, 2) apply_block_kernel(ApplyArgs a, BlockP
     A.ent = A.ent; // (A holds pass gp)
     BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entA2 = entry(gp + 2);
-    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds);
+    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm);
     finish_pass();
     if (gp >= gp_end) break;
     A.ent = entA2;
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entB2 = entry(gp + 2);
-    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds);
+    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm);
     finish_pass();
     B.ent = entB2;
   }

@@ -470,3 +470,89 @@ def test_single_rank_communicator_and_distributed_entry_points():
     assert rel(d.cpu().numpy(), pr.vmult(s.cpu().numpy())) < TOL_OP
     op.mf_data.synchronize()
     comm.close()
+
+
+# ------------------------------------------------------------------ edge cases
+def test_single_cell_and_tiny_meshes():
+    """one cell (every DoF on the Dirichlet boundary except the interior ones), p = 1 and p = 8"""
+    for p in (1, 4, 8):
+        pr = O.Problem(p, (1, 1, 1), 0, deform_amp=0.0)
+        op = pkg.PoissonOperator(pkg.BrickMesh(p, (1, 1, 1)), 0)
+        s = O.deterministic_src(pr.mesh.n_dofs, seed=1)
+        d = op.initialize_dof_vector()
+        op.vmult(d, dev(s))
+        assert rel(d.cpu().numpy(), pr.vmult(s)) < TOL_OP
+        b = op.assemble_rhs()
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(3, 0.0)
+        if p == 1:                                   # no interior DoF: b == 0 -> converged at step 0
+            pkg.SolverCG(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+            assert ctl.last_step() == 0 and float(x.abs().max()) == 0.0
+        else:
+            pkg.SolverCG(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+            xr, k, _ = O.cg_plain(pr.vmult, pr.rhs(), 3)
+            assert rel(x.cpu().numpy(), xr) < TOL_CG
+
+
+def test_zero_rhs_and_zero_iterations():
+    op = pkg.PoissonOperator(pkg.BrickMesh(2, (3, 3, 3)), 0)
+    b = op.initialize_dof_vector()                   # b = 0: residual 0 <= tol -> 0 iterations, x = 0
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        x.fill_(3.0)
+        ctl = pkg.IterationNumberControl(5, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == 0 and float(x.abs().max()) == 0.0
+    b = op.assemble_rhs()
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):   # max_iter = 0: returns the initial guess 0
+        x = op.initialize_dof_vector()
+        x.fill_(3.0)
+        ctl = pkg.IterationNumberControl(0, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == 0 and float(x.abs().max()) == 0.0
+        assert abs(ctl.last_value() - float(b.norm())) < 1e-12 * float(b.norm())
+
+
+def test_cg_breakdown_is_reported_not_thrown_across_the_abi():
+    """p.Ap == 0 (here: an all-zero metric) must surface as BP5_ERR_BREAKDOWN (ExcDivideByZero,
+    bp5/solver.h:501), through the status code."""
+    torch = _t()
+    op = pkg.PoissonOperator(pkg.BrickMesh(2, (2, 2, 2)), 0)
+    op.coef.zero_()
+    b = op.assemble_rhs()
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        with pytest.raises(pkg.BP5Error) as e:
+            solver(pkg.IterationNumberControl(5, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+        assert e.value.status == 6
+
+
+def test_argument_validation():
+    torch = _t()
+    import ctypes as C
+    mesh = pkg.BrickMesh(2, (2, 2, 2))
+    op = pkg.PoissonOperator(mesh, 0)
+    x = op.initialize_dof_vector()
+    short = torch.zeros(5, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(pkg.BP5Error):
+        op.vmult(short, x)                           # too short
+    with pytest.raises(pkg.BP5Error):
+        op.vmult(x, x.float())                       # wrong dtype
+    L, h = pkg.lib(), op.mf_data.handle
+    p = lambda t: C.c_void_p(t.data_ptr())
+    odd = torch.zeros(mesh.n_owned + 1, dtype=torch.float64, device="cuda:0")[1:]   # 8-byte but not 16-byte aligned
+    assert L.bp5_vec_axpy(h, p(odd), 1.0, p(x), 4) == 1
+    assert L.bp5_apply(h, None, p(x), p(x), 1) == 1
+    assert L.bp5_mf_set_apply_variant(h, 77) == 0 and L.bp5_apply(h, p(op.coef), p(x), p(op.initialize_dof_vector()), 1) == 1
+    # a corrupt local_to_global is rejected on the host, before anything reaches the GPU
+    from deal_and_ceed_on_gpu_amd import _lib
+    bad = mesh.l2g.copy()
+    bad[0, 0] = mesh.n_local + 5
+    d = _lib.MFDesc()
+    d.dim, d.degree, d.quadrature = 3, 2, 0
+    d.n_cells, d.n_interior_cells, d.n_owned, d.n_ghost = mesh.n_cells, mesh.n_cells, mesh.n_owned, 0
+    xyz, cst = np.ascontiguousarray(mesh.coords), np.ascontiguousarray(mesh.constrained)
+    d.local_to_global_host, d.node_coords_host, d.constrained_host = bad.ctypes.data, xyz.ctypes.data, cst.ctypes.data
+    d.n_constrained = cst.size
+    hh = C.c_void_p()
+    assert L.bp5_mf_create(C.byref(d), C.byref(hh)) == 1
