@@ -120,7 +120,6 @@ def main():
 
     # warm-up
     Solver(pkg.IterationNumberControl(max(args.warmup, 1), 0.0), profile=True).solve(op, x, b, precond)
-    Solver(pkg.IterationNumberControl(args.steps, 0.0), profile=True).solve(op, x, b, precond) if False else None
     barrier()
     ctl = pkg.IterationNumberControl(args.steps, 0.0)
     solver = Solver(ctl, profile=True)
@@ -165,11 +164,15 @@ def main():
                          "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p, quad, (40, 40, 40) if p == 4 else (16, 16, 16), 20, args.deform, km)
+            # bounded sample of the same workload family: ~10 s of host CPU work
+            out["cpu_baseline"] = cpu_baseline(p, quad, (48, 48, 48) if p <= 4 else (24, 24, 24), 40, args.deform, km)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        torch.cuda.synchronize()
         dist.barrier()
+        op.mf_data.close()
+        comm.close()
         dist.destroy_process_group()
 
 
