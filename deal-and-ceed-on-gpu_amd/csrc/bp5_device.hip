@@ -47,7 +47,7 @@ struct bp5_mf {
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0;
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
-  bool force_atomic_scatter = false;
+  bool force_atomic_scatter = false, block_shared_atomic = false;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   Tables tab, tab_gauss;
@@ -477,6 +477,24 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   const dim3 grid(n_wg), block(256);
+  if (mf->block_shared_atomic) {
+    // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
+    if (set && dp->n_shared) {
+      hipLaunchKernelGGL(zero_indexed_kernel, dim3((dp->n_shared + 255) / 256), dim3(256), 0, mf->stream, dp->sh_dof, dp->n_shared, dst);
+      KERNEL_CHECK();
+    }
+    if (set) {
+      auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET_ATOMIC, ABL>;
+      HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+    } else {
+      auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD_ATOMIC, ABL>;
+      HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+    }
+    KERNEL_CHECK();
+    return BP5_OK;
+  }
   if (set) {
     auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET, ABL>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -561,11 +579,22 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
       return coll_ ? launch_team_t<4, true, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite)
                    : launch_team_t<4, false, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite);
     }
+    if (mf->degree == 4 && whole && (mf->apply_variant == 54 || mf->apply_variant == 55)) {
+      mf->block_shared_atomic = true;
+      const int st_ = mf->apply_variant == 54 ? (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                                       : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
+                                              : (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                                       : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
+      mf->block_shared_atomic = false;
+      return st_;
+    }
     if (mf->degree == 4 && whole && (mf->apply_variant == 50 || mf->apply_variant == 51))
       return mf->apply_variant == 50 ? (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
                                               : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
                                      : (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
                                               : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
+    if (mf->degree == 4 && mf->apply_variant == 85) // timing only: affine, no scatter atomics -> compute/latency floor of the pencil kernel
+      return launch_apply_t<4, false, 4, 25, 1, true, 1025>(mf, mf->d_scalar_plane, src, dst, c0, c1);
     if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     switch (mf->degree) {
       case 1: return launch_affine<1>(mf, src, dst, c0, c1);
@@ -627,10 +656,15 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     case 408: return coll ? launch_apply_t<4, true, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
     case 409: return coll ? launch_apply_t<4, true, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
     case 482: return launch_apply_t<4, false, 4, 25, 1, true, 257>(mf, coef, src, dst, c0, c1);
+    case 483: return launch_apply_t<4, false, 4, 25, 1, true, 4096>(mf, coef, src, dst, c0, c1);
+    case 484: return launch_apply_t<4, false, 4, 25, 1, true, 8192>(mf, coef, src, dst, c0, c1);
     case 480: return launch_apply_t<4, false, 4, 25, 1, true, 64>(mf, coef, src, dst, c0, c1);
     case 481: { // E-vector stores need a big scratch target
       if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
       return launch_apply_t<4, false, 4, 25, 1, true, 128>(mf, coef, src, mf->d_evec, c0, c1); }
+    case 486: {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 128 + 16384>(mf, coef, src, mf->d_evec, c0, c1); }
     ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(5); ABL_CASE(7); ABL_CASE(8); ABL_CASE(9); ABL_CASE(15); ABL_CASE(14); ABL_CASE(13); ABL_CASE(11);
     // block-assembled kernel (compact cell blocks, LDS accumulator, no atomics), variants 50+;
     // a partial cell range cannot use the owner scatter and takes the atomic team kernel instead
@@ -645,6 +679,15 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     BLOCK_CASE(3, 50, 16, 4, true);
     BLOCK_CASE(4, 50, 25, 4, true);
     BLOCK_CASE(4, 51, 32, 4, true);
+    case 454: case 455:
+      if (c0 == 0 && c1 == mf->n_cells) {
+        mf->block_shared_atomic = true;
+        const int st_ = variant == 454 - 400 ? (coll ? launch_block_t<4, true, 32>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32>(mf, coef, src, dst, overwrite))
+                                             : (coll ? launch_block_t<4, true, 25>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25>(mf, coef, src, dst, overwrite));
+        mf->block_shared_atomic = false;
+        return st_;
+      }
+      return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
     case 452: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
     case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
@@ -1001,7 +1044,7 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   // kernels that accumulate with atomics need a zeroed target: do the fill outside the profiled bracket so
   // that the bracket times the cell kernel alone (owner-scatter kernels define every entry themselves)
   const int v = mf->apply_variant % 100;
-  const bool owner_scatter = mf->apply_variant < 100 && (v == 10 || v == 11 || v == 12 || v == 13 || v == 14 || v == 50 || v == 51 || v == 52 || v == 53 ||
+  const bool owner_scatter = mf->apply_variant < 100 && (v == 10 || v == 11 || v == 12 || v == 13 || v == 14 || v == 50 || v == 51 || v == 52 || v == 53 || v == 54 || v == 55 ||
                                                          (mf->apply_variant == 0 && (mf->degree == 1 || mf->degree == 3)));
   if (zero && !owner_scatter) {
     HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));

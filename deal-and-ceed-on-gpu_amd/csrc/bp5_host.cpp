@@ -229,6 +229,28 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
         nr = std::max<uint8_t>(nr, r + 1);
         passes[(size_t)pick * cells_per_pass + fill[pick]++] = c;
       }
+      // merge under-full passes pairwise: the cells of the absorbed pass run in a later round of the
+      // absorbing pass (e.g. 4x4x2 bricks: 8 parity classes of 4 cells -> 4 passes of 8 cells, 2 rounds)
+      for (bool merged = true; merged;) {
+        merged = false;
+        for (int qa = 0; qa < (int)fill.size() && !merged; ++qa)
+          for (int qb = (int)fill.size() - 1; qb > qa; --qb)
+            if (fill[qa] > 0 && fill[qb] > 0 && fill[qa] + fill[qb] <= cells_per_pass) {
+              uint8_t ra = 0;
+              for (int k = 0; k < fill[qa]; ++k) ra = std::max<uint8_t>(ra, out.cell_round[passes[(size_t)qa * cells_per_pass + k]]);
+              for (int k = 0; k < fill[qb]; ++k) {
+                const uint32_t cb = passes[(size_t)qb * cells_per_pass + k];
+                out.cell_round[cb] = (uint8_t)(out.cell_round[cb] + ra + 1);
+                nr = std::max<uint8_t>(nr, out.cell_round[cb] + 1);
+                passes[(size_t)qa * cells_per_pass + fill[qa]++] = cb;
+              }
+              // drop pass qb
+              passes.erase(passes.begin() + (size_t)qb * cells_per_pass, passes.begin() + (size_t)(qb + 1) * cells_per_pass);
+              fill.erase(fill.begin() + qb);
+              merged = true;
+              break;
+            }
+      }
       out.team_rounds[t] = nr;
       // idle slots repeat the pass's first cell, flagged by bit 31
       for (size_t q = 0; q < fill.size(); ++q)

@@ -328,6 +328,21 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
 #pragma unroll
     for (int k = 0; k < n; ++k) acc += y[k];
     if (acc == 1.2345e300) a.dst[idx[0]] = acc; // keeps y live, never taken
+  } else if constexpr (ABL & 4096) { // timing only: 64-bit integer atomics on the bit pattern
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k)
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.dst) + idx[k], (unsigned long long)__double_as_longlong(y[k]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if constexpr (ABL & 8192) { // timing only: two f32 atomics per value (hi/lo words)
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) {
+        float *pf = reinterpret_cast<float *>(a.dst + idx[k]);
+        __hip_atomic_fetch_add(pf, (float)y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   } else if constexpr (ABL & 64) { // timing only: plain scattered stores instead of atomics
     if (active) {
 #pragma unroll
@@ -336,7 +351,10 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
   } else if constexpr (ABL & 128) { // timing only: contiguous E-vector stores (a.dst must hold n_cells*n^3 doubles)
     if (active) {
 #pragma unroll
-      for (int k = 0; k < n; ++k) a.dst[cell * n3 + k * n2 + abm] = y[k];
+      for (int k = 0; k < n; ++k) {
+        if constexpr (ABL & 16384) __builtin_nontemporal_store(y[k], a.dst + cell * n3 + k * n2 + abm);
+        else a.dst[cell * n3 + k * n2 + abm] = y[k];
+      }
     }
   } else if (active) {
 #pragma unroll
@@ -372,7 +390,10 @@ struct TeamPlan {
 // The OWNER modes need every team of the plan to run in the launch; combine_kernel then finishes
 // the shared DoFs in a fixed order, so the whole operator is free of atomics and bitwise
 // reproducible.
-enum { SC_ATOMIC = 0, SC_OWNER_SET = 1, SC_OWNER_ADD = 2 };
+//   SC_OWNER_SET_ATOMIC / SC_OWNER_ADD_ATOMIC  exclusive DoFs as above, shared DoFs by one global atomic per
+//                 (group, DoF): no partial slab and no combine pass; the caller zeroes the shared DoFs first
+//                 in SET mode.  Order-dependent rounding on group-surface DoFs only.
+enum { SC_ATOMIC = 0, SC_OWNER_SET = 1, SC_OWNER_ADD = 2, SC_OWNER_SET_ATOMIC = 3, SC_OWNER_ADD_ATOMIC = 4 };
 
 __device__ __forceinline__ void lds_add_f64(double *p, double v)
 {
@@ -931,10 +952,11 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
               const double v = acc[i];
               if (g & 0x80000000u) {
                 if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[g & 0x7fffffffu] = v; }
-                else if constexpr (SCATTER == SC_OWNER_SET) __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
+                else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
                 else a.dst[g & 0x7fffffffu] += v;
               } else {
                 if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
+                else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + g, v);
                 else __builtin_nontemporal_store(v, bp.partial + o0 + i);
               }
             }
@@ -1189,6 +1211,12 @@ __global__ void __launch_bounds__(256) combine_kernel(const uint32_t *sh_dof, co
   for (uint32_t j = b + 1; j < e; ++j) s += partial[sh_slot[j]];
   const uint32_t g = sh_dof[i];
   if (ADD) dst[g] += s; else dst[g] = s;
+}
+
+__global__ void __launch_bounds__(256) zero_indexed_kernel(const uint32_t *idx, uint32_t n, double *dst)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) dst[idx[i]] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------ small vector kernels

@@ -93,7 +93,7 @@ def test_cell_loop_all_degrees(p, quad):
 
 @pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1),
                                        (1, 10), (2, 10), (3, 10), (4, 10), (4, 11), (4, 12), (4, 13), (5, 10), (6, 10), (7, 10), (8, 10),
-                                       (1, 50), (2, 50), (3, 50), (4, 50), (4, 51), (5, 50), (6, 50), (7, 50), (8, 50), (4, 110)])
+                                       (1, 50), (2, 50), (3, 50), (4, 50), (4, 51), (5, 50), (6, 50), (7, 50), (8, 50), (4, 110), (4, 52), (4, 53), (4, 54), (4, 55)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_kernel_variants(p, variant, quad):
     cells = (7, 3, 1) if p <= 5 else (5, 1, 1)
@@ -206,7 +206,7 @@ def test_affine_geometry_mode(p, quad):
         assert rel(x.cpu().numpy(), xr) < TOL_CG
 
 
-@pytest.mark.parametrize("variant,block,numbering", [(10, (0, 0, 0), 0), (110, (0, 0, 0), 0), (50, (4, 4, 4), 1), (51, (4, 4, 2), 0)])
+@pytest.mark.parametrize("variant,block,numbering", [(10, (0, 0, 0), 0), (110, (0, 0, 0), 0), (50, (4, 4, 4), 1), (51, (4, 4, 2), 0), (54, (4, 4, 4), 1), (55, (4, 4, 4), 0)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_affine_mode_team_and_block_kernels(variant, block, numbering, quad):
     p, cells = 4, (8, 5, 4)
