@@ -165,7 +165,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             # bounded sample of the same workload family: ~10 s of host CPU work
-            out["cpu_baseline"] = cpu_baseline(p, quad, (48, 48, 48) if p <= 4 else (24, 24, 24), 40, args.deform, km)
+            out["cpu_baseline"] = cpu_baseline(p, quad, (48, 48, 48) if p <= 4 else (24, 24, 24), 120, args.deform, km)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

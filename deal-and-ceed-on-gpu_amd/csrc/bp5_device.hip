@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -45,7 +46,7 @@ struct bp5_event {
 struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
-  int apply_variant = 0, n_cus = 0, geometry_mode = 0;
+  int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
   bool force_atomic_scatter = false, block_shared_atomic = false;
   hipStream_t stream = nullptr;
@@ -67,6 +68,7 @@ struct bp5_mf {
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
   double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr, *d_evec = nullptr;
+  char *ws_base = nullptr;
   double *h_sc = nullptr; // pinned
   int *h_st = nullptr;    // pinned
   std::vector<hipEvent_t> ev_pool;
@@ -82,6 +84,8 @@ struct bp5_mf {
     bool covers_all = false;
   };
   std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
+  struct DevMarch { uint32_t *team_off = nullptr, *entries = nullptr; uint32_t n_teams = 0; };
+  std::map<int, DevMarch> march_plans; // keyed by cells per team
   std::map<int, DevPlan> plans;
   size_t n_local() const { return (size_t)n_owned + n_ghost; }
 };
@@ -199,11 +203,12 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_g, mf->ws_d, mf->ws_h, mf->d_evec, mf->d_scalar_plane, mf->d_gcell};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_evec, mf->d_scalar_plane, mf->d_gcell};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
   for (hipEvent_t e : mf->ev_pool) hipEventDestroy(e);
+  for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
     void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off};
@@ -551,6 +556,40 @@ static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
     return coll ? launch_team_t<P, true, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)                       \
                 : launch_team_t<P, false, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)
 
+// z-marching kernel (whole cell range only; partial ranges take the plain pencil kernel)
+template <int P, bool COLL, int TW, int LPC, bool PF, int ABL = 0>
+static int launch_march_t(bp5_mf *mf, const double *coef, const double *src, double *dst)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 64 * TW / LPC;
+  using L = LdsLayout<n, LPC>;
+  auto it = mf->march_plans.find(CPT);
+  if (it == mf->march_plans.end()) {
+    MarchPlanHost h;
+    BP5_TRY(build_march_plan(mf->h_l2g.data(), mf->n_cells, n, CPT, mf->march_max_steps, h));
+    bp5_mf::DevMarch dm;
+    BP5_TRY(upload(&dm.team_off, h.team_off.data(), h.team_off.size()));
+    BP5_TRY(upload(&dm.entries, h.entries.data(), h.entries.size()));
+    dm.n_teams = (uint32_t)h.team_off.size() - 1;
+    it = mf->march_plans.emplace(CPT, dm).first;
+  }
+  MarchPlan mp;
+  mp.team_off = it->second.team_off; mp.entries = it->second.entries; mp.n_teams = it->second.n_teams;
+  mp.teams_per_xcd = (mp.n_teams + 7) / 8;
+  ApplyArgs a;
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = mp.n_teams; a.teams_per_xcd = mp.teams_per_xcd;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const size_t lds = (size_t)CPT * L::CS * sizeof(double);
+  hipLaunchKernelGGL((apply_march_kernel<P, COLL, TW, LPC, PF, ABL>), dim3(mp.teams_per_xcd * 8), dim3(64 * TW), lds, mf->stream, a, mp, sh);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+
 // variant table: (degree, variant) -> (TW, LPC, TPB, PF); variant 0 = default for the degree
 #define APPLY_CASE(P, V, TW, LPC, TPB, PF)                                                                         \
   case (P)*100 + (V):                                                                                              \
@@ -666,6 +705,26 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
       if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
       return launch_apply_t<4, false, 4, 25, 1, true, 128 + 16384>(mf, coef, src, mf->d_evec, c0, c1); }
     ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(5); ABL_CASE(7); ABL_CASE(8); ABL_CASE(9); ABL_CASE(15); ABL_CASE(14); ABL_CASE(13); ABL_CASE(11);
+    // z-marching kernel, variants 70+ (atomic scatter: dst must be zero-filled like for the pencil kernel)
+#define MARCH_CASE(P, V, TW, LPC, PF)                                                                              \
+  case (P)*100 + (V):                                                                                              \
+    if (overwrite && hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream) != hipSuccess)             \
+      return fail(BP5_ERR_HIP, "hipMemsetAsync");                                                                  \
+    if (c0 != 0 || c1 != mf->n_cells)                                                                              \
+      return coll ? launch_apply_t<P, true, TW, LPC, 1, PF>(mf, coef, src, dst, c0, c1)                            \
+                  : launch_apply_t<P, false, TW, LPC, 1, PF>(mf, coef, src, dst, c0, c1);                          \
+    return coll ? launch_march_t<P, true, TW, LPC, PF>(mf, coef, src, dst) : launch_march_t<P, false, TW, LPC, PF>(mf, coef, src, dst)
+    case 473: return launch_march_t<4, false, 4, 25, true, 1>(mf, coef, src, dst); // timing only: march, no scatter
+    MARCH_CASE(1, 70, 4, 4, true);
+    MARCH_CASE(2, 70, 4, 9, true);
+    MARCH_CASE(3, 70, 4, 16, true);
+    MARCH_CASE(4, 70, 4, 25, true);
+    MARCH_CASE(4, 71, 2, 25, true);
+    MARCH_CASE(4, 72, 1, 25, true);
+    MARCH_CASE(5, 70, 4, 36, true);
+    MARCH_CASE(6, 70, 4, 49, true);
+    MARCH_CASE(7, 70, 4, 64, true);
+    MARCH_CASE(8, 70, 4, 81, true);
     // block-assembled kernel (compact cell blocks, LDS accumulator, no atomics), variants 50+;
     // a partial cell range cannot use the owner scatter and takes the atomic team kernel instead
 #define BLOCK_CASE(P, V, LPC, TW_FALLBACK, PF)                                                                     \
@@ -1004,13 +1063,17 @@ extern "C" int bp5_event_destroy(bp5_event *e)
 static int ensure_ws(bp5_mf *mf)
 {
   if (mf->ws_g) return BP5_OK;
-  const size_t nb = std::max<size_t>(mf->n_local(), 2) * sizeof(double);
-  HIP_TRY(hipMalloc((void **)&mf->ws_g, nb));
-  HIP_TRY(hipMalloc((void **)&mf->ws_d, nb));
-  HIP_TRY(hipMalloc((void **)&mf->ws_h, nb));
-  HIP_TRY(hipMemset(mf->ws_g, 0, nb));
-  HIP_TRY(hipMemset(mf->ws_d, 0, nb));
-  HIP_TRY(hipMemset(mf->ws_h, 0, nb));
+  // one allocation for the three work vectors (staggering their bases by 256 B ... 1 MiB was measured
+  // to make no difference to the BLAS-1 kernels: profiles/r1/README.md)
+  const size_t stagger = 0;
+  const size_t nb = (std::max<size_t>(mf->n_local(), 2) * sizeof(double) + 4095) / 4096 * 4096;
+  char *base = nullptr;
+  HIP_TRY(hipMalloc((void **)&base, 3 * nb + 2 * stagger + 4096));
+  HIP_TRY(hipMemset(base, 0, 3 * nb + 2 * stagger + 4096));
+  mf->ws_base = base;
+  mf->ws_g = (double *)base;
+  mf->ws_d = (double *)(base + nb + stagger);
+  mf->ws_h = (double *)(base + 2 * nb + 2 * stagger);
   return BP5_OK;
 }
 

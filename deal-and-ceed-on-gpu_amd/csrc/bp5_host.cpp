@@ -280,6 +280,62 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
   }
   return BP5_OK;
 }
+
+// ---------------------------------------------------------------------------------- z-marching plan
+int build_march_plan(const uint32_t *l2g, uint32_t n_cells, int n, int cpt, int max_steps, MarchPlanHost &out)
+{
+  const int n2 = n * n, n3 = n2 * n;
+  // successor of a cell: the cell whose bottom layer (k = 0) has exactly the DoFs of this cell's top layer.
+  // key = (first, last) DoF of the layer, verified by full comparison
+  std::vector<std::pair<uint64_t, uint32_t>> bottoms(n_cells);
+  for (uint32_t c = 0; c < n_cells; ++c) bottoms[c] = {((uint64_t)l2g[(size_t)c * n3] << 32) | l2g[(size_t)c * n3 + n2 - 1], c};
+  std::sort(bottoms.begin(), bottoms.end());
+  std::vector<uint32_t> succ(n_cells, 0xffffffffu);
+  std::vector<uint8_t> has_pred(n_cells, 0);
+  for (uint32_t c = 0; c < n_cells; ++c) {
+    const uint32_t *top = l2g + (size_t)c * n3 + (size_t)(n - 1) * n2;
+    const uint64_t key = ((uint64_t)top[0] << 32) | top[n2 - 1];
+    auto it = std::lower_bound(bottoms.begin(), bottoms.end(), std::make_pair(key, 0u));
+    for (; it != bottoms.end() && it->first == key; ++it) {
+      const uint32_t d = it->second;
+      if (d != c && !has_pred[d] && std::equal(top, top + n2, l2g + (size_t)d * n3)) { succ[c] = d; has_pred[d] = 1; break; }
+    }
+  }
+  // chains, cut into segments of at most max_steps cells; segment heads in cell order
+  std::vector<std::vector<uint32_t>> segs;
+  for (uint32_t c = 0; c < n_cells; ++c) {
+    if (has_pred[c]) continue;
+    std::vector<uint32_t> cur;
+    for (uint32_t d = c; d != 0xffffffffu; d = succ[d]) {
+      cur.push_back(d);
+      if ((int)cur.size() == max_steps) { segs.push_back(cur); cur.clear(); }
+    }
+    if (!cur.empty()) segs.push_back(cur);
+  }
+  // sort segments by their head cell so that teams take neighbouring columns
+  std::sort(segs.begin(), segs.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
+  const size_t n_teams = (segs.size() + cpt - 1) / cpt;
+  out.team_off.assign(n_teams + 1, 0);
+  for (size_t t = 0; t < n_teams; ++t) {
+    size_t steps = 0;
+    for (size_t k = t * cpt; k < std::min(segs.size(), (t + 1) * (size_t)cpt); ++k) steps = std::max(steps, segs[k].size());
+    out.team_off[t + 1] = out.team_off[t] + (uint32_t)steps;
+  }
+  out.entries.assign((size_t)out.team_off[n_teams] * cpt, 0x80000000u);
+  for (size_t t = 0; t < n_teams; ++t) {
+    const size_t steps = out.team_off[t + 1] - out.team_off[t];
+    for (int sl = 0; sl < cpt; ++sl) {
+      const size_t k = t * cpt + sl;
+      for (size_t st = 0; st < steps; ++st) {
+        uint32_t &e = out.entries[((size_t)out.team_off[t] + st) * cpt + sl];
+        if (k < segs.size() && st < segs[k].size()) e = segs[k][st] | (st > 0 ? 0x40000000u : 0u);
+        else e = (k < segs.size() ? segs[k][0] : segs[t * cpt][0]) | 0x80000000u; // idle: any valid cell id
+      }
+    }
+  }
+  if (n_cells >= 0x40000000u) return fail(BP5_ERR_UNSUPPORTED, "march plan needs fewer than 2^30 cells");
+  return BP5_OK;
+}
 } // namespace bp5
 
 using namespace bp5;

@@ -37,4 +37,13 @@ struct TeamPlanHost {
 int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_local, int cpt, TeamPlanHost &out,
                     const uint32_t *blk_off = nullptr, uint32_t n_blocks = 0, int cells_per_pass = 0);
 
+// z-marching plan (apply_march_kernel): cells are linked into chains along their local z direction
+// (the k = n-1 face of a cell is the k = 0 face of its successor); `cpt` chains advance together.
+// entry(team, step, slot) = cell id | flags: bit 31 idle slot, bit 30 "linked to the previous step"
+struct MarchPlanHost {
+  std::vector<uint32_t> team_off; // [n_teams+1] offsets (in steps) into entries / cpt
+  std::vector<uint32_t> entries;  // [total_steps * cpt]
+};
+int build_march_plan(const uint32_t *l2g, uint32_t n_cells, int n, int cpt, int max_steps, MarchPlanHost &out);
+
 } // namespace bp5

@@ -363,6 +363,275 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
 #undef TL
 }
 
+// ------------------------------------------------------------------------------------ fused operator, z-marching
+// Same per-cell arithmetic and launch shape as apply_pencil_kernel, but a workgroup walks CPT chains of
+// cells along their local z direction (host plan: build_march_plan).  A lane's pencil runs along z, so the
+// contribution to the shared face  y[n-1]  stays in a register and is added to  y[0]  of the next cell, and
+// u[n-1] is reused as the next u[0]: n^2 (n-1) instead of n^3 gathers and -- the point -- memory-side
+// atomics per cell (the default kernel is bound by their count: DESIGN.md 5).
+struct MarchPlan {
+  const uint32_t *team_off; // [n_teams+1] in steps
+  const uint32_t *entries;  // [steps * CPT]: cell | bit31 idle | bit30 linked to the previous step
+  uint32_t n_teams, teams_per_xcd;
+};
+
+template <int P, bool COLL, int TW, int LPC, bool PF, int ABL = 0>
+__global__ void __launch_bounds__(64 * TW) apply_march_kernel(ApplyArgs a, MarchPlan mp, ShapeArg<P + 1> sh)
+{
+  constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
+  constexpr int TEAM = 64 * TW;
+  constexpr int CPT = TEAM / LPC;
+  static_assert(LPC >= n2 && CPT >= 1, "lanes per cell");
+  using L = LdsLayout<n, LPC>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int t = threadIdx.x;
+  const int c = t / LPC, ab = t - c * LPC;
+  const uint32_t team = (blockIdx.x & 7u) * mp.teams_per_xcd + (blockIdx.x >> 3);
+  if (team >= mp.n_teams) return; // whole workgroup
+  const bool lane_ok = (ab < n2) && (c < CPT);
+  const int slot = c < CPT ? c : 0;
+  const int abm = ab < n2 ? ab : ab % n2;
+  const int a_ = abm % n, b_ = abm / n;
+  double *T = lds + slot * L::CS;
+#define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]
+
+  const uint32_t s0 = mp.team_off[team], s1 = mp.team_off[team + 1];
+  uint32_t e_next = mp.entries[(uint64_t)s0 * CPT + slot];
+  uint32_t e_next2 = mp.entries[(uint64_t)(s0 + 1 < s1 ? s0 + 1 : s0) * CPT + slot];
+  double u_carry = 0.0, y_carry = 0.0;
+  uint32_t idx_carry = 0;
+  // software pipeline: idxN / uN hold layers 1..n-1 of the NEXT step's cell (layer 0 too when it starts a chain)
+  uint32_t idxN[n];
+  double uN[n];
+  {
+    const uint32_t *l2g_n = a.l2g + (uint64_t)(e_next & 0x3fffffffu) * n3 + abm;
+#pragma unroll
+    for (int k = 0; k < n; ++k) idxN[k] = l2g_n[k * n2];
+#pragma unroll
+    for (int k = 0; k < n; ++k) uN[k] = a.src[idxN[k]];
+  }
+  for (uint32_t st = s0; st < s1; ++st) {
+    const uint32_t e = e_next;
+    e_next = e_next2;
+    e_next2 = st + 2 < s1 ? mp.entries[(uint64_t)(st + 2) * CPT + slot] : 0x80000000u;
+    if (st + 1 >= s1) e_next = 0x80000000u | (e & 0x3fffffffu);
+    const bool active = lane_ok && !(e >> 31);
+    const bool linked = (e >> 30) & 1u;                              // k = 0 layer == previous cell's k = n-1 layer
+    const bool next_linked = !(e_next >> 31) && ((e_next >> 30) & 1u); // this cell's k = n-1 layer is continued
+    const uint64_t cell = e & 0x3fffffffu;
+
+    // ---- gather (z-owner: a_ = i, b_ = j; registers hold k); a linked cell reuses the carried face
+    uint32_t idx[n];
+    double u[n];
+    idx[0] = linked ? idx_carry : idxN[0];
+    u[0] = linked ? u_carry : uN[0];
+#pragma unroll
+    for (int k = 1; k < n; ++k) { idx[k] = idxN[k]; u[k] = uN[k]; }
+    u_carry = u[n - 1];
+    idx_carry = idx[n - 1];
+    // indices of the next step's cell (its layer 0 is only needed when it starts a new chain, but loading it
+    // unconditionally keeps the lanes converged)
+    {
+      const uint32_t *l2g_n = a.l2g + (uint64_t)(e_next & 0x3fffffffu) * n3 + abm;
+#pragma unroll
+      for (int k = 0; k < n; ++k) idxN[k] = l2g_n[k * n2];
+    }
+
+    // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
+    const double *cf = a.coef + cell * n3 + abm;
+    constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
+    double S[(PF && !AFFINE) ? 6 : 1][n];
+    double Gc[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (AFFINE) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) S[0][i] = cf[i * n2];
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
+    } else if constexpr (PF) {
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl)
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+          S[pl][i] = (ABL & 2) ? 1.0 + pl + i + 1e-3 * abm
+                               : (ABL & 256) ? __builtin_nontemporal_load(cf + pl * a.plane_stride + i * n2) : cf[pl * a.plane_stride + i * n2];
+    }
+
+    double g0[n], g1[n], g2[n];
+    if constexpr (ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { g0[i] = u[i]; g1[i] = 2.0 * u[i]; g2[i] = 3.0 * u[i]; }
+    } else if constexpr (!COLL) {
+      // z-pass in registers
+      double aN[n], aD[n];
+      MV_N(sh.N, u, aN);
+      MV_D(sh.D, u, aD);
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = aN[k]; TL(1, k, b_, a_) = aD[k]; }
+      }
+      team_sync<TW>();
+      // y-owner: a_ = i, b_ = k
+      double vN[n], vD[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) { vN[j] = TL(0, b_, j, a_); vD[j] = TL(1, b_, j, a_); }
+      double c1[n], c2[n], c3[n];
+      MV_N(sh.N, vN, c1);
+      MV_D(sh.D, vN, c2);
+      MV_N(sh.N, vD, c3);
+      team_sync<TW>();
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = c1[j]; TL(1, b_, j, a_) = c2[j]; TL(2, b_, j, a_) = c3[j]; }
+      }
+      team_sync<TW>();
+      // x-owner: a_ = j, b_ = k
+      double r1[n], r2[n], r3[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        r1[i] = TL(0, b_, a_, i);
+        r2[i] = TL(1, b_, a_, i);
+        r3[i] = TL(2, b_, a_, i);
+      }
+      MV_D(sh.D, r1, g0);
+      MV_N(sh.N, r2, g1);
+      MV_N(sh.N, r3, g2);
+    } else {
+      // collocation: g0 = Dx u, g1 = Dy u, g2 = Dz u
+      double gz[n];
+      MV_D(sh.D, u, gz);
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = u[k]; TL(2, k, b_, a_) = gz[k]; }
+      }
+      team_sync<TW>();
+      double vN[n], c2[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) vN[j] = TL(0, b_, j, a_);
+      MV_D(sh.D, vN, c2);
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) TL(1, b_, j, a_) = c2[j];
+      }
+      team_sync<TW>();
+      double r1[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        r1[i] = TL(0, b_, a_, i);
+        g1[i] = TL(1, b_, a_, i);
+        g2[i] = TL(2, b_, a_, i);
+      }
+      MV_D(sh.D, r1, g0);
+    }
+
+    // the next step's indices have landed: start its src gather
+#pragma unroll
+    for (int k = 0; k < n; ++k) uN[k] = a.src[idxN[k]];
+
+    // ---- quadrature-point operation: t = S ghat (symmetric 3x3, bp5/step-64.cu:166-177)
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      double s00, s11, s22, s01, s02, s12;
+      if constexpr (AFFINE) {
+        const double sc = S[0][i];
+        s00 = sc * Gc[0]; s11 = sc * Gc[1]; s22 = sc * Gc[2]; s01 = sc * Gc[3]; s02 = sc * Gc[4]; s12 = sc * Gc[5];
+      } else if constexpr (PF) {
+        s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
+      } else {
+        s00 = cf[0 * a.plane_stride + i * n2];
+        s11 = cf[1 * a.plane_stride + i * n2];
+        s22 = cf[2 * a.plane_stride + i * n2];
+        s01 = cf[3 * a.plane_stride + i * n2];
+        s02 = cf[4 * a.plane_stride + i * n2];
+        s12 = cf[5 * a.plane_stride + i * n2];
+      }
+      const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
+      g0[i] = s00 * x0 + s01 * x1 + s02 * x2;
+      g1[i] = s01 * x0 + s11 * x1 + s12 * x2;
+      g2[i] = s02 * x0 + s12 * x1 + s22 * x2;
+    }
+
+    // ---- integrate (transpose sequence)
+    double y[n];
+    if constexpr (ABL & 8) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) y[i] = g0[i] + g1[i] + g2[i];
+    } else if constexpr (!COLL) {
+      double e1[n], e2[n], e3[n];
+      MV_DT(sh.D, g0, e1);
+      MV_NT(sh.N, g1, e2);
+      MV_NT(sh.N, g2, e3);
+      team_sync<TW>();
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = e2[i]; TL(2, b_, a_, i) = e3[i]; }
+      }
+      team_sync<TW>();
+      double w1[n], w2[n], w3[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        w1[j] = TL(0, b_, j, a_);
+        w2[j] = TL(1, b_, j, a_);
+        w3[j] = TL(2, b_, j, a_);
+      }
+      double f1[n], f2[n];
+      MV_NT(sh.N, w1, f1);
+      MV_DT_ADD(sh.D, w2, f1);
+      MV_NT(sh.N, w3, f2);
+      team_sync<TW>();
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = f1[j]; TL(1, b_, j, a_) = f2[j]; }
+      }
+      team_sync<TW>();
+      double z1[n], z2[n];
+#pragma unroll
+      for (int k = 0; k < n; ++k) { z1[k] = TL(0, k, b_, a_); z2[k] = TL(1, k, b_, a_); }
+      MV_NT(sh.N, z1, y);
+      MV_DT_ADD(sh.D, z2, y);
+    } else {
+      double e1[n];
+      MV_DT(sh.D, g0, e1);
+      team_sync<TW>();
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = g1[i]; TL(2, b_, a_, i) = g2[i]; }
+      }
+      team_sync<TW>();
+      double w1[n], w2[n];
+#pragma unroll
+      for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); }
+      MV_DT_ADD(sh.D, w2, w1);
+      if (active) { // each y-owner lane rewrites only the column it has just read
+#pragma unroll
+        for (int j = 0; j < n; ++j) TL(0, b_, j, a_) = w1[j];
+      }
+      team_sync<TW>();
+      double z2[n];
+#pragma unroll
+      for (int k = 0; k < n; ++k) { y[k] = TL(0, k, b_, a_); z2[k] = TL(2, k, b_, a_); }
+      MV_DT_ADD(sh.D, z2, y);
+    }
+
+
+    // ---- scatter: the carried face of the previous cell joins k = 0; the k = n-1 layer is held back when
+    //      the chain continues
+    if constexpr (ABL & 1) { // timing only: no scatter
+      double sacc = y_carry;
+#pragma unroll
+      for (int k = 0; k < n; ++k) sacc += y[k];
+      if (sacc == 1.2345e300) a.dst[idx[0]] = sacc;
+    } else if (active) {
+      if (linked) y[0] += y_carry;
+#pragma unroll
+      for (int k = 0; k < n - 1; ++k) atomic_add_f64(a.dst + idx[k], y[k]);
+      if (!next_linked) atomic_add_f64(a.dst + idx[n - 1], y[n - 1]);
+    }
+    y_carry = y[n - 1];
+  }
+#undef TL
+}
+
 // ------------------------------------------------------------------------------------ fused operator, team-assembled
 // Same arithmetic as apply_pencil_kernel, but gather and scatter go through the team's LDS:
 //   * the host builds, per team of CPT consecutive cells, the sorted list of the distinct DoFs the

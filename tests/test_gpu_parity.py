@@ -239,6 +239,36 @@ def test_affine_mode_rejects_deformed_mesh():
     mf2.set_geometry_mode(pkg.GEOM_AFFINE)
 
 
+@pytest.mark.parametrize("p,cells,variant", [(1, (3, 2, 40), 70), (2, (5, 3, 6), 70), (3, (4, 3, 5), 70), (4, (7, 3, 5), 70), (4, (3, 3, 4), 71),
+                                             (4, (5, 2, 3), 72), (5, (3, 2, 4), 70), (6, (3, 2, 3), 70), (7, (2, 2, 3), 70), (8, (2, 1, 3), 70)])
+@pytest.mark.parametrize("quad", [0, 1])
+def test_march_kernel(p, cells, variant, quad):
+    """z-marching kernel: chains longer than the segment cap (p = 1: 40 cells in z, cap 32), ragged teams,
+    deformed mesh, block-major numbering on one case; operator, accumulate mode and CG."""
+    numbering, block = (1, (2, 2, 2)) if (p == 3) else (0, (0, 0, 0))
+    pr = O.Problem(p, cells, quad, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, cell_block=block, dof_numbering=numbering)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
+    op.mf_data.set_apply_variant(variant)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=23)
+    src = dev(s[perm])
+    dst = op.initialize_dof_vector()
+    dst.fill_(float("nan"))
+    op.vmult(dst, src)
+    assert rel(dst.cpu().numpy(), pr.vmult(s)[perm]) < TOL_OP
+    acc = op.initialize_dof_vector()
+    op.mf_data.cell_loop(op.coef, src, acc)
+    op.mf_data.cell_loop(op.coef, src, acc)
+    assert rel(acc.cpu().numpy(), 2 * O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]) < TOL_OP
+    b = op.assemble_rhs()
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 6)
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(6, 0.0)
+    pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+    assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+
+
 def test_vmult_dirichlet_and_zero_out_flag():
     p, cells = 3, (3, 3, 3)
     pr = O.Problem(p, cells, 0, deform_amp=0.05)
