@@ -69,6 +69,7 @@ struct bp5_mf {
   int *d_st = nullptr;
   double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr, *d_evec = nullptr;
   char *ws_base = nullptr;
+  unsigned long long *d_stamps = nullptr;
   double *h_sc = nullptr; // pinned
   int *h_st = nullptr;    // pinned
   std::vector<hipEvent_t> ev_pool;
@@ -203,7 +204,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_evec, mf->d_scalar_plane, mf->d_gcell};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
@@ -471,6 +472,12 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (dp->n_groups + 7) / 8 * 8) / 8 * 8);
   bp.n_wg = n_wg;
+  bp.stamps = nullptr;
+  if (ABL & 4096) {
+    if (!mf->d_stamps) HIP_TRY(hipMalloc((void **)&mf->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(mf->d_stamps, 0, 4096 * 16 * sizeof(unsigned long long), mf->stream));
+    bp.stamps = mf->d_stamps;
+  }
   ApplyArgs a;
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
@@ -510,6 +517,17 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
   }
   KERNEL_CHECK();
+  if (ABL & 4096) { // diagnostic build: print the per-phase cycle shares (never quote its run time)
+    HIP_TRY(hipStreamSynchronize(mf->stream));
+    std::vector<unsigned long long> hs((size_t)n_wg * 16);
+    HIP_TRY(hipMemcpy(hs.data(), mf->d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double tot[9] = {0};
+    for (uint32_t w = 0; w < n_wg; ++w) for (int k = 0; k < 9; ++k) tot[k] += (double)hs[(size_t)w * 16 + k];
+    double all = 0; for (int k = 0; k < 7; ++k) all += tot[k];
+    static const char *nm[7] = {"issue loads", "evaluate (+wait u)", "wait idx + issue gather", "q-op (+wait metric)", "integrate", "accumulate", "block boundary"};
+    fprintf(stderr, "[bp5 stamps] passes/wg %.1f, cycles/pass %.0f\n", tot[8] / n_wg, all / tot[8]);
+    for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
+  }
   if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass (1024/2048 are real modes)
   return launch_combine(mf, dp, dst, set);
 }
@@ -701,6 +719,15 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     case 481: { // E-vector stores need a big scratch target
       if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
       return launch_apply_t<4, false, 4, 25, 1, true, 128>(mf, coef, src, mf->d_evec, c0, c1); }
+    case 490: {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, ((size_t)mf->n_cells * mf->n3 + 4096 * 5) * sizeof(double) * 2));
+      return launch_apply_t<4, false, 4, 25, 1, true, 262144>(mf, coef, src, mf->d_evec, c0, c1); }
+    case 488: {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 128 + 65536>(mf, coef, src, mf->d_evec, c0, c1); }
+    case 489: {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 1 + 131072>(mf, coef, src, mf->d_evec, c0, c1); }
     case 486: {
       if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
       return launch_apply_t<4, false, 4, 25, 1, true, 128 + 16384>(mf, coef, src, mf->d_evec, c0, c1); }
@@ -751,6 +778,8 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
       return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
     case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 53 needs the whole cell range");
+    case 497: return launch_block_t<4, false, 32, 4096>(mf, coef, src, dst, true);          // stamps, double-buffered
+    case 498: return launch_block_t<4, false, 32, 4096 + 2048>(mf, coef, src, dst, true);   // stamps, single-buffered
     case 492: return launch_block_t<4, false, 32, 2049>(mf, coef, src, dst, true);
     case 496: return launch_block_t<4, false, 32, 2053>(mf, coef, src, dst, true);
     BLOCK_CASE(5, 50, 36, 4, true);

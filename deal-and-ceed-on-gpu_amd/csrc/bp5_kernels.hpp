@@ -151,6 +151,12 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
 #pragma unroll
   for (int k = 0; k < n; ++k) u[k] = (ABL & 4) ? 1e-9 * idx[k] : a.src[idx[k]];
 
+  if constexpr (ABL & 131072) { // timing only: the E-vector-sized write stream issued at the START of the workgroup
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) a.dst[cell * n3 + k * n2 + abm] = u[k];
+    }
+  }
   // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
   const double *cf = a.coef + cell * n3 + abm;
   constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
@@ -348,10 +354,13 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
 #pragma unroll
       for (int k = 0; k < n; ++k) a.dst[idx[k]] = y[k];
     }
+  } else if constexpr (ABL & 262144) { // timing only: full-line stores: lane-contiguous, 512 B per wave instruction
+#pragma unroll
+    for (int k = 0; k < n; ++k) a.dst[((uint64_t)k * a.n_teams + team) * TEAM + t] = y[k];
   } else if constexpr (ABL & 128) { // timing only: contiguous E-vector stores (a.dst must hold n_cells*n^3 doubles)
     if (active) {
 #pragma unroll
-      for (int k = 0; k < n; ++k) {
+      for (int k = 0; k < ((ABL & 65536) ? 1 : n); ++k) {
         if constexpr (ABL & 16384) __builtin_nontemporal_store(y[k], a.dst + cell * n3 + k * n2 + abm);
         else a.dst[cell * n3 + k * n2 + abm] = y[k];
       }
@@ -935,6 +944,7 @@ struct BlockPlan {
   const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
   double *partial;            // [off[n_blocks]]
   uint32_t n_blocks, n_wg;    // persistent workgroups, n_wg a multiple of 8
+  unsigned long long *stamps; // diagnostic builds only: [n_wg][16] cycle sums per phase (never read by kernels)
 };
 
 // register set of one pass (cell ids, positions, gathered values, metric)
@@ -950,6 +960,22 @@ struct PassRegs {
   bool active;
 };
 
+// cycle stamp for diagnostic builds (MI355X guide: "In-kernel stamps"): one asm statement, fenced
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define BP5_STAMP(slot)                                                                                            \
+  if constexpr (ABL & 4096) {                                                                                      \
+    const unsigned long long now_ = stamp_now();                                                                   \
+    ph[slot] += now_ - tprev;                                                                                      \
+    tprev = now_;                                                                                                  \
+  }
+
 template <int P, bool COLL, int LPC, int SCATTER, int ABL>
 struct BlockPass {
   static constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
@@ -961,6 +987,13 @@ struct BlockPass {
   // indices / gathered values are prefetched one pass ahead: ~60 fewer VGPRs -> three workgroups per CU
   static constexpr bool SINGLE = (ABL & 2048) != 0;
   using R = PassRegs<n, AFFINE>;
+  // all lanes of a cell slot sit in one wave when LPC divides 64: the tile exchanges then need no block barrier
+  static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
+  static __device__ __forceinline__ void tile_sync()
+  {
+    if constexpr (WAVE_LOCAL) team_sync<1>();
+    else __syncthreads();
+  }
 
   // issue index / position / metric loads of the cell named by r.ent
   static __device__ __forceinline__ void issue_loads(const ApplyArgs &a, const BlockPlan &bp, R &r, int abm, bool lane_ok, bool exists)
@@ -1001,9 +1034,10 @@ struct BlockPass {
   // one pass: compute with `cur`, keep the loads of `nxt` in flight.  Returns nothing; all
   // block bookkeeping is done by the caller.
   static __device__ __forceinline__ void run(const ApplyArgs &a, const ShapeArg<n> &sh, R &cur, R &nxt, double *T, double *acc, int a_, int b_,
-                                             int n_rounds, int abm)
+                                             int n_rounds, int abm, unsigned long long (&ph)[8], unsigned long long &tprev)
   {
     if constexpr (SINGLE) issue_metric(a, cur, abm);
+    BP5_STAMP(0) // issue of this pass's loads
 #define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]
     const bool active = cur.active;
     double(&u)[n] = cur.u;
@@ -1019,7 +1053,7 @@ struct BlockPass {
 #pragma unroll
         for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = aN[k]; TL(1, k, b_, a_) = aD[k]; }
       }
-      __syncthreads();
+      tile_sync();
       double vN[n], vD[n];
 #pragma unroll
       for (int j = 0; j < n; ++j) { vN[j] = TL(0, b_, j, a_); vD[j] = TL(1, b_, j, a_); }
@@ -1027,12 +1061,12 @@ struct BlockPass {
       MV_N(sh.N, vN, c1);
       MV_D(sh.D, vN, c2);
       MV_N(sh.N, vD, c3);
-      __syncthreads();
+      tile_sync();
       if (active) {
 #pragma unroll
         for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = c1[j]; TL(1, b_, j, a_) = c2[j]; TL(2, b_, j, a_) = c3[j]; }
       }
-      __syncthreads();
+      tile_sync();
       double r1[n], r2[n], r3[n];
 #pragma unroll
       for (int i = 0; i < n; ++i) { r1[i] = TL(0, b_, a_, i); r2[i] = TL(1, b_, a_, i); r3[i] = TL(2, b_, a_, i); }
@@ -1046,7 +1080,7 @@ struct BlockPass {
 #pragma unroll
         for (int k = 0; k < n; ++k) { TL(0, k, b_, a_) = u[k]; TL(2, k, b_, a_) = gz[k]; }
       }
-      __syncthreads();
+      tile_sync();
       double vN[n], c2[n];
 #pragma unroll
       for (int j = 0; j < n; ++j) vN[j] = TL(0, b_, j, a_);
@@ -1055,15 +1089,17 @@ struct BlockPass {
 #pragma unroll
         for (int j = 0; j < n; ++j) TL(1, b_, j, a_) = c2[j];
       }
-      __syncthreads();
+      tile_sync();
       double r1[n];
 #pragma unroll
       for (int i = 0; i < n; ++i) { r1[i] = TL(0, b_, a_, i); g1[i] = TL(1, b_, a_, i); g2[i] = TL(2, b_, a_, i); }
       MV_D(sh.D, r1, g0);
     }
 
+    BP5_STAMP(1) // evaluate (z/y/x contractions; its first use of u waits for the gather)
     // the index loads of the next pass have landed by now: start its src gather
     issue_gather(a, nxt);
+    BP5_STAMP(2) // wait for the next pass's indices + issue of its gather
 
 #pragma unroll
     for (int i = 0; i < n; ++i) {
@@ -1080,6 +1116,7 @@ struct BlockPass {
       }
     }
 
+    BP5_STAMP(3) // quadrature-point operation (first use of the metric: waits for its loads)
     double y[n];
     if constexpr (ABL & 8) {
 #pragma unroll
@@ -1089,12 +1126,12 @@ struct BlockPass {
       MV_DT(sh.D, g0, e1);
       MV_NT(sh.N, g1, e2);
       MV_NT(sh.N, g2, e3);
-      __syncthreads();
+      tile_sync();
       if (active) {
 #pragma unroll
         for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = e2[i]; TL(2, b_, a_, i) = e3[i]; }
       }
-      __syncthreads();
+      tile_sync();
       double w1[n], w2[n], w3[n];
 #pragma unroll
       for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); w3[j] = TL(2, b_, j, a_); }
@@ -1102,12 +1139,12 @@ struct BlockPass {
       MV_NT(sh.N, w1, f1);
       MV_DT_ADD(sh.D, w2, f1);
       MV_NT(sh.N, w3, f2);
-      __syncthreads();
+      tile_sync();
       if (active) {
 #pragma unroll
         for (int j = 0; j < n; ++j) { TL(0, b_, j, a_) = f1[j]; TL(1, b_, j, a_) = f2[j]; }
       }
-      __syncthreads();
+      tile_sync();
       double z1[n], z2[n];
 #pragma unroll
       for (int k = 0; k < n; ++k) { z1[k] = TL(0, k, b_, a_); z2[k] = TL(1, k, b_, a_); }
@@ -1116,12 +1153,12 @@ struct BlockPass {
     } else {
       double e1[n];
       MV_DT(sh.D, g0, e1);
-      __syncthreads();
+      tile_sync();
       if (active) {
 #pragma unroll
         for (int i = 0; i < n; ++i) { TL(0, b_, a_, i) = e1[i]; TL(1, b_, a_, i) = g1[i]; TL(2, b_, a_, i) = g2[i]; }
       }
-      __syncthreads();
+      tile_sync();
       double w1[n], w2[n];
 #pragma unroll
       for (int j = 0; j < n; ++j) { w1[j] = TL(0, b_, j, a_); w2[j] = TL(1, b_, j, a_); }
@@ -1130,22 +1167,25 @@ struct BlockPass {
 #pragma unroll
         for (int j = 0; j < n; ++j) TL(0, b_, j, a_) = w1[j];
       }
-      __syncthreads();
+      tile_sync();
       double z2[n];
 #pragma unroll
       for (int k = 0; k < n; ++k) { y[k] = TL(0, k, b_, a_); z2[k] = TL(2, k, b_, a_); }
       MV_DT_ADD(sh.D, z2, y);
     }
 
+    BP5_STAMP(4) // integrate
     // accumulate into the block's LDS vector; cells of one round share no DoF (normally the
     // whole pass is one round: host packing, bp5_host.cpp)
+    // One block barrier per round, BEFORE the update: it orders this pass's accumulation after the previous
+    // pass's (cells of different passes may share DoFs and run on different waves).
     if constexpr (!(ABL & 1)) {
       for (int rd = 0; rd < n_rounds; ++rd) {
+        __syncthreads();
         if (active && cur.round == rd) {
 #pragma unroll
           for (int k = 0; k < n; ++k) acc[cur.ps[k]] += y[k];
         }
-        __syncthreads();
       }
     } else {
       double sacc = 0.0;
@@ -1154,6 +1194,7 @@ struct BlockPass {
       if (sacc == 1.2345e300) acc[cur.ps[0]] = sacc;
       __syncthreads();
     }
+    BP5_STAMP(5) // accumulate
 #undef TL
   }
 };
@@ -1197,39 +1238,54 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
 
   // two register sets, used alternately (loop unrolled by two): the loads of pass q+1 are issued
   // at the top of pass q and first waited for inside pass q+1
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  if constexpr (ABL & 4096) tprev = stamp_now();
   PassRegs<n, (ABL & 1024) != 0> A, B;
   A.ent = entry(gp);
   B.ent = entry(gp + 1);
   BP::issue_loads(a, bp, A, abm, lane_ok, true);
   BP::issue_gather(a, A);
 
-  // end-of-pass bookkeeping: when a block is finished, write it out and re-arm the accumulator
+  // end-of-pass bookkeeping: when a block is finished, write it out and re-arm the accumulator.  The block's
+  // DoF list is prefetched into registers at the top of its last pass (prefetch_list), so the write-out does
+  // not wait on dependent loads; entries beyond MAXW per thread (very large blocks) take the slow path.
+  constexpr int MAXW = (ABL & 2048) ? 1 : 6; // registers are scarce (the single-buffered build is capped at 168)
+  uint32_t gl[MAXW];
+  auto prefetch_list = [&]() {
+    if (gp + 1 == boundary) {
+#pragma unroll
+      for (int r = 0; r < MAXW; ++r) gl[r] = (t + r * TEAM < m) ? bp.dofs[o0 + t + r * TEAM] : 0u;
+    }
+  };
+  auto emit = [&](int i, uint32_t g) {
+    const double v = acc[i];
+    acc[i] = 0.0; // re-arm for the next block (invariant: the accumulator is all zero between blocks)
+    if (g & 0x80000000u) {
+      if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[g & 0x7fffffffu] = v; }
+      else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
+      else a.dst[g & 0x7fffffffu] += v;
+    } else {
+      if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
+      else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + g, v);
+      else __builtin_nontemporal_store(v, bp.partial + o0 + i);
+    }
+  };
   auto finish_pass = [&]() {
     if (gp + 1 == boundary) {
+      __syncthreads(); // every wave has added its last contributions of this block
       if constexpr (!(ABL & 1)) {
-        // the list entries are loaded eight at a time so that their latency is paid once per
-        // batch, not once per entry
-        for (int base = t; base < m; base += 8 * TEAM) {
-          uint32_t gl[8];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) gl[r] = (base + r * TEAM < m) ? bp.dofs[o0 + base + r * TEAM] : 0u;
+        for (int r = 0; r < MAXW; ++r) {
+          const int i = t + r * TEAM;
+          if (i < m) emit(i, gl[r]);
+        }
+        for (int base = t + MAXW * TEAM; base < m; base += 8 * TEAM) { // remainder: batches of eight loads
+          uint32_t g8[8];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int i = base + r * TEAM;
-            if (i < m) {
-              const uint32_t g = gl[r];
-              const double v = acc[i];
-              if (g & 0x80000000u) {
-                if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[g & 0x7fffffffu] = v; }
-                else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
-                else a.dst[g & 0x7fffffffu] += v;
-              } else {
-                if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
-                else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + g, v);
-                else __builtin_nontemporal_store(v, bp.partial + o0 + i);
-              }
-            }
-          }
+          for (int r = 0; r < 8; ++r) g8[r] = (base + r * TEAM < m) ? bp.dofs[o0 + base + r * TEAM] : 0u;
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (base + r * TEAM < m) emit(base + r * TEAM, g8[r]);
         }
       }
       ++b;
@@ -1237,29 +1293,37 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
         boundary = bp.pass_off[b + 1];
         o0 = bp.off[b];
         m = (int)(bp.off[b + 1] - o0);
-        const int nr = bp.blk_rounds[b];
-        __syncthreads(); // the old sums have been read
-        for (int i = t; i < m; i += TEAM) acc[i] = 0.0;
-        __syncthreads();
-        n_rounds = nr;
+        n_rounds = bp.blk_rounds[b];
       }
+      // no barrier here: the next pass starts with tile work and reaches the accumulation barrier before it
+      // touches the accumulator again
     }
     ++gp;
   };
 
   while (gp < gp_end) {
-    A.ent = A.ent; // (A holds pass gp)
+    prefetch_list();
     BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entA2 = entry(gp + 2);
-    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm);
+    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm, ph, tprev);
     finish_pass();
+    BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
     A.ent = entA2;
+    prefetch_list();
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entB2 = entry(gp + 2);
-    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm);
+    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev);
     finish_pass();
+    BP5_STAMP(6)
     B.ent = entB2;
+  }
+  if constexpr (ABL & 4096) {
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bp.stamps[(uint64_t)w * 16 + k] = ph[k];
+      bp.stamps[(uint64_t)w * 16 + 8] = gp_end - bp.pass_off[(uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg)];
+    }
   }
 }
 

@@ -15,11 +15,13 @@ ap.add_argument("--degrees", type=int, nargs="+", default=list(range(1, 9)))
 ap.add_argument("--variants", type=int, nargs="+", default=[0])
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--deform", type=float, default=0.0)
+ap.add_argument("--cell-block", type=int, nargs=3, default=[0, 0, 0])
+ap.add_argument("--numbering", type=int, default=0)
 a = ap.parse_args()
 rows = []
 for p in a.degrees:
     ncell = max(2, int(round((a.dofs ** (1 / 3) - 1) / p)))
-    mesh = pkg.BrickMesh(p, (ncell,) * 3, h=1.0 / ncell, deform_amp=a.deform)
+    mesh = pkg.BrickMesh(p, (ncell,) * 3, h=1.0 / ncell, deform_amp=a.deform, cell_block=a.cell_block, dof_numbering=a.numbering)
     n = mesh.n_owned
     r = mesh.n_cells * (p + 1) ** 3 / n
     B_op, B = 16 + 52 * r, 16 + 52 * r + 88
