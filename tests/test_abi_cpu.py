@@ -156,3 +156,12 @@ def test_block_major_numbering(p, cells, block, n_ranks):
             assert len(sent) == NX * NY and len(set(sent // (NX * NY))) == 1
     allowned = np.concatenate(all_owned)
     assert len(allowned) == o.n_dofs and len(np.unique(allowned)) == o.n_dofs
+
+
+def test_pure_c_consumer_of_the_abi():
+    """include/bp5.h is valid C11 and libbp5.so links from a C program (tests/c/abi_smoke.c)."""
+    import subprocess
+    cdir = os.path.join(bp5_pkg.ROOT, "tests", "c")
+    subprocess.check_call(["make", "-s", "-C", cdir])
+    r = subprocess.run([os.path.join(cdir, "abi_smoke")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
