@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--apply-variant", type=int, default=0)
     ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6",
                     help="merged6: the reference's six stored planes per q-point (G=6, default); affine: per-cell metric + one scalar plane (G=1), affine meshes only")
+    ap.add_argument("--cell-block", type=int, nargs=3, default=None,
+                    help="hand the cells over in bricks of this many cells (default: 4 4 4 at p=4 -> block-assembled kernel; "
+                         "0 0 0 = lexicographic cell order -> pencil kernel with atomics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,7 +104,12 @@ def main():
     quad = pkg.QUAD_GAUSS if args.quadrature == "gauss" else pkg.QUAD_GLL
     km = pkg.COEF_STEP64 if args.coefficient == "step64" else pkg.COEF_ONE
 
-    mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world)
+    # cell order / DoF numbering are the host's choice (the reference's MatrixFree::reinit reorders cells too): bricks of
+    # 4x4x4 cells, parity-class order inside a brick, brick-major DoF numbering -> the library picks its block kernel
+    block = tuple(args.cell_block) if args.cell_block else ((4, 4, 4) if p == 4 else (0, 0, 0))
+    blocked = all(b > 0 for b in block)
+    mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world,
+                         cell_block=block if blocked else (0, 0, 0), dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0)
     G = 6 if args.geometry == "merged6" else 1
     op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
                              geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
@@ -143,7 +151,8 @@ def main():
         B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
         achieved = B_op * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
-        key = f"p{p}_{args.quadrature}_{cells_per_gpu[0]}x{cells_per_gpu[1]}x{cells_per_gpu[2]}_{args.geometry}_v{args.apply_variant}"
+        ev = op.mf_data.get_apply_variant()
+        key = f"p{p}_{args.quadrature}_{cells_per_gpu[0]}x{cells_per_gpu[1]}x{cells_per_gpu[2]}_{args.geometry}_v{ev}"
         tr = measured_traffic(key) if args.deform == 0.0 else None
         out = {
             "metric": "BP5 DoFs/sec per CG iter (p=4, ~1e8 DoFs) + % HBM roofline at 1/2/4/8 GPUs",
@@ -153,7 +162,8 @@ def main():
             "config": {"workload": f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
-                       "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world}"},
+                       "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world}",
+                       "cell_block": list(block) if blocked else None, "apply_variant": ev},
             "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
                             "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS},
             # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs) / average time between the HIP

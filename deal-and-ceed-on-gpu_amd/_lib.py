@@ -45,7 +45,7 @@ HEADER_SYMBOLS = _header_symbols()
 
 class MeshDesc(C.Structure):
     _fields_ = [("degree", C.c_int), ("cells", C.c_uint32 * 3), ("h", C.c_double), ("deform_amp", C.c_double),
-                ("rank", C.c_int), ("n_ranks", C.c_int), ("cell_block", C.c_uint32 * 3), ("dof_numbering", C.c_int)]
+                ("rank", C.c_int), ("n_ranks", C.c_int), ("cell_block", C.c_uint32 * 3), ("dof_numbering", C.c_int), ("cell_block_order", C.c_int)]
 
 
 class MeshView(C.Structure):
@@ -125,6 +125,7 @@ def lib():
         "bp5_copy_constrained": (i32, [vp, vp, vp]),
         "bp5_set_constrained": (i32, [vp, f64, vp]),
         "bp5_mf_set_apply_variant": (i32, [vp, i32]),
+        "bp5_mf_get_apply_variant": (i32, [vp, C.POINTER(C.c_int)]),
         "bp5_assemble_rhs": (i32, [vp, vp]),
         "bp5_l2_norm_solution": (i32, [vp, vp, C.POINTER(f64)]),
         "bp5_vec_fill": (i32, [vp, vp, f64, sz]),

@@ -47,6 +47,7 @@ struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
+  int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
   bool force_atomic_scatter = false, block_shared_atomic = false;
   hipStream_t stream = nullptr;
@@ -242,6 +243,15 @@ extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
 {
   if (!mf) return fail(BP5_ERR_INVALID, "null handle");
   mf->apply_variant = v;
+  return BP5_OK;
+}
+
+static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1);
+extern "C" int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective)
+{
+  if (!mf || !effective) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  *effective = effective_variant(mf, 0, mf->n_cells);
   return BP5_OK;
 }
 
@@ -457,7 +467,8 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   using L = LdsLayout<n, LPC>;
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -CPT, &dp));
-  const size_t lds = ((size_t)CPT * L::CS + dp->max_list) * sizeof(double);
+  const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
+  const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double);
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
   BlockPlan bp;
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos;
@@ -528,7 +539,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     fprintf(stderr, "[bp5 stamps] passes/wg %.1f, cycles/pass %.0f\n", tot[8] / n_wg, all / tot[8]);
     for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
   }
-  if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass (1024/2048 are real modes)
+  if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
   return launch_combine(mf, dp, dst, set);
 }
 
@@ -626,7 +637,35 @@ static int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0
   return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<P, true, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1)
                                         : launch_apply_t<P, false, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1);
 }
-static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite = false)
+// Variant 0 = library default.  The measured choices (profiles/r1): p = 1, 3 x-row team kernel; p = 4 on a mesh
+// handed over in cell blocks that fit three workgroups per CU: block-assembled kernel (no atomics, no zero-fill,
+// bitwise reproducible), whole cell range only; p = 4 affine geometry: team kernel; everything else: pencil kernel.
+static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
+{
+  const int v = mf->apply_variant;
+  if (v != 0) return v;
+  if (mf->degree == 1 || mf->degree == 3) return mf->geometry_mode == BP5_GEOM_AFFINE ? 0 : 10;
+  if (mf->degree != 4) return 0;
+  if (mf->geometry_mode == BP5_GEOM_AFFINE) return 10;
+  if (c0 != 0 || c1 != mf->n_cells || mf->h_block_off.empty()) return 0;
+  if (mf->auto_block < 0) {
+    bp5_mf::DevPlan *dp = nullptr;
+    mf->auto_block = 0;
+    if (get_plan_raw(mf, -8, &dp, 64) == BP5_OK) {
+      const size_t lds = ((size_t)8 * (5 * LdsLayout<5, 32>::PS + 3) + dp->max_list) * sizeof(double);
+      mf->auto_block = lds * 3 <= 160 * 1024;
+    }
+  }
+  return mf->auto_block ? 56 : 0;
+}
+// kernels that define every entry of dst themselves (owner stores + combine pass) need no zero-fill
+static bool variant_overwrites(const bp5_mf *mf, int ev)
+{
+  const int v = ev % 100;
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 50 && v <= 58)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+}
+
+static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
 {
   if (mf->geometry_mode == BP5_GEOM_AFFINE && c1 > c0) {
     const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
@@ -672,8 +711,6 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
   // variants >= 100: the team kernel of (variant - 100) with the global-atomic scatter (A/B tests)
   mf->force_atomic_scatter = mf->apply_variant >= 100;
   int variant = mf->apply_variant % 100;
-  // library defaults from the degree sweep (profiles/r1): x-row team kernel for p = 1 and 3
-  if (mf->apply_variant == 0 && (mf->degree == 1 || mf->degree == 3)) variant = 10;
   switch (mf->degree * 100 + variant) {
     APPLY_CASE(1, 0, 1, 4, 4, true);
     APPLY_CASE(1, 1, 1, 4, 4, true);
@@ -774,6 +811,13 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
         return st_;
       }
       return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
+    case 456: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 56 needs the whole cell range");
+    case 457: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 8192>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 57 needs the whole cell range");
+    case 458: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 58 needs the whole cell range");
+    case 499: return launch_block_t<4, false, 32, 4096 + 2048 + 8192>(mf, coef, src, dst, true);   // stamps, sequential tiles, 3 WG/CU
     case 452: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
     case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
@@ -816,6 +860,14 @@ static int launch_apply(bp5_mf *mf, const double *coef, const double *src, doubl
     TEAM_CASE(8, 10, 4, 81, false);
   }
   return fail(BP5_ERR_INVALID, "unknown (degree, apply variant)");
+}
+static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite = false)
+{
+  const int user = mf->apply_variant;
+  mf->apply_variant = effective_variant(mf, c0, c1);
+  const int st = launch_apply_impl(mf, coef, src, dst, c0, c1, overwrite);
+  mf->apply_variant = user;
+  return st;
 }
 
 extern "C" int bp5_apply_cells(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
@@ -1135,9 +1187,7 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   if (dist) BP5_TRY(bp5_halo_gather(mf, src));
   // kernels that accumulate with atomics need a zeroed target: do the fill outside the profiled bracket so
   // that the bracket times the cell kernel alone (owner-scatter kernels define every entry themselves)
-  const int v = mf->apply_variant % 100;
-  const bool owner_scatter = mf->apply_variant < 100 && (v == 10 || v == 11 || v == 12 || v == 13 || v == 14 || v == 50 || v == 51 || v == 52 || v == 53 || v == 54 || v == 55 ||
-                                                         (mf->apply_variant == 0 && (mf->degree == 1 || mf->degree == 3)));
+  const bool owner_scatter = variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells));
   if (zero && !owner_scatter) {
     HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     zero = false;

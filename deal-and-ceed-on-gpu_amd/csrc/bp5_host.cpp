@@ -413,6 +413,7 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   const uint64_t zi0_ = z0 + (r > 0 ? 1 : 0);
   const bool blocked_ = d->cell_block[0] && d->cell_block[1] && d->cell_block[2];
   if (d->dof_numbering == 1 && !blocked_) { delete m; return fail(BP5_ERR_INVALID, "block-major numbering needs cell_block"); }
+  if (d->cell_block_order != 0 && (d->cell_block_order != 1 || !blocked_)) { delete m; return fail(BP5_ERR_INVALID, "cell_block_order must be 0, or 1 with cell_block"); }
   // per direction: slots are alternately block-boundary planes (length 1) and the runs between them
   struct Dir {
     std::vector<uint8_t> kind;      // per coordinate (relative to lo): 1 = plane, 0 = run
@@ -487,18 +488,25 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   const uint64_t bx = blocked ? d->cell_block[0] : n0, by = blocked ? d->cell_block[1] : 1, bz = blocked ? d->cell_block[2] : 1;
   size_t c = 0;
   m->block_off.push_back(0);
+  const bool class_major = blocked && d->cell_block_order == 1;
   auto emit_region = [&](uint64_t za, uint64_t zb) {
     for (uint64_t Z = za; Z < zb; Z += bz)
       for (uint64_t Y = 0; Y < n1; Y += by)
         for (uint64_t X = 0; X < n0; X += bx) {
-          for (uint64_t z = Z; z < std::min(Z + bz, zb); ++z)
-            for (uint64_t y = Y; y < std::min(Y + by, n1); ++y)
-              for (uint64_t x = X; x < std::min(X + bx, n0); ++x, ++c) {
-                uint32_t *dst = &m->l2g[c * nl];
-                for (int k = 0; k < n; ++k)
-                  for (int j = 0; j < n; ++j)
-                    for (int i = 0; i < n; ++i) dst[i + n * (j + n * k)] = local_of(p * x + i, p * y + j, p * z + k);
-              }
+          // inside a brick: lexicographic, or parity class by parity class so that the cells of one conflict-free
+          // pass of the block kernel are consecutive in memory
+          const int n_cls = class_major ? 8 : 1;
+          for (int cls = 0; cls < n_cls; ++cls)
+            for (uint64_t z = Z; z < std::min(Z + bz, zb); ++z)
+              for (uint64_t y = Y; y < std::min(Y + by, n1); ++y)
+                for (uint64_t x = X; x < std::min(X + bx, n0); ++x) {
+                  if (class_major && (int)(((x - X) & 1) | (((y - Y) & 1) << 1) | (((z - Z) & 1) << 2)) != cls) continue;
+                  uint32_t *dst = &m->l2g[c * nl];
+                  for (int k = 0; k < n; ++k)
+                    for (int j = 0; j < n; ++j)
+                      for (int i = 0; i < n; ++i) dst[i + n * (j + n * k)] = local_of(p * x + i, p * y + j, p * z + k);
+                  ++c;
+                }
           if (blocked) m->block_off.push_back((uint32_t)c);
         }
   };

@@ -989,6 +989,11 @@ struct BlockPass {
   using R = PassRegs<n, AFFINE>;
   // all lanes of a cell slot sit in one wave when LPC divides 64: the tile exchanges then need no block barrier
   static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
+  // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
+  // workgroup needs a third of the tile memory: 4x4x4 accumulator + tiles = 47 KB -> three workgroups per CU
+  static constexpr bool SEQ = (ABL & 8192) != 0;
+  static_assert(!SEQ || WAVE_LOCAL, "sequential tiles need wave-local cells");
+  static constexpr int TILE_CS = SEQ ? (n * L::PS + 3) : L::CS; // doubles per cell slot
   static __device__ __forceinline__ void tile_sync()
   {
     if constexpr (WAVE_LOCAL) team_sync<1>();
@@ -1022,7 +1027,8 @@ struct BlockPass {
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl)
 #pragma unroll
-        for (int i = 0; i < n; ++i) r.S[pl][i] = (ABL & 2) ? 1.0 + pl + i : cf[pl * a.plane_stride + i * n2];
+        for (int i = 0; i < n; ++i)
+          r.S[pl][i] = (ABL & 2) ? 1.0 + pl + i : (ABL & 32768) ? __builtin_nontemporal_load(&cf[pl * a.plane_stride + i * n2]) : cf[pl * a.plane_stride + i * n2];
     }
   }
   static __device__ __forceinline__ void issue_gather(const ApplyArgs &a, R &r)
@@ -1038,6 +1044,215 @@ struct BlockPass {
   {
     if constexpr (SINGLE) issue_metric(a, cur, abm);
     BP5_STAMP(0) // issue of this pass's loads
+    if constexpr (SEQ) {
+#define T1(k, j, i) T[(k) * L::PS + (j) * L::RS + (i)]
+      const bool act = cur.active;
+      double(&uu)[n] = cur.u;
+      double q0[n], q1[n], q2[n];
+      if constexpr (!COLL) {
+        double aN[n], aD[n], vN[n], vD[n];
+        MV_N(sh.N, uu, aN);
+        MV_D(sh.D, uu, aD);
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < n; ++k) T1(k, b_, a_) = aN[k];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) vN[j] = T1(b_, j, a_);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < n; ++k) T1(k, b_, a_) = aD[k];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) vD[j] = T1(b_, j, a_);
+        tile_sync();
+        double c1[n], c2[n], c3[n], r1[n], r2[n], r3[n];
+        MV_N(sh.N, vN, c1);
+        MV_D(sh.D, vN, c2);
+        MV_N(sh.N, vD, c3);
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = c1[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int i = 0; i < n; ++i) r1[i] = T1(b_, a_, i);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = c2[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int i = 0; i < n; ++i) r2[i] = T1(b_, a_, i);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = c3[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int i = 0; i < n; ++i) r3[i] = T1(b_, a_, i);
+        tile_sync();
+        MV_D(sh.D, r1, q0);
+        MV_N(sh.N, r2, q1);
+        MV_N(sh.N, r3, q2);
+      } else {
+        double gz[n], vN[n], c2[n], r1[n];
+        MV_D(sh.D, uu, gz);
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < n; ++k) T1(k, b_, a_) = uu[k];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) vN[j] = T1(b_, j, a_);
+#pragma unroll
+        for (int i = 0; i < n; ++i) r1[i] = T1(b_, a_, i);
+        tile_sync();
+        MV_D(sh.D, vN, c2);
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = c2[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int i = 0; i < n; ++i) q1[i] = T1(b_, a_, i);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < n; ++k) T1(k, b_, a_) = gz[k];
+        }
+        tile_sync();
+#pragma unroll
+        for (int i = 0; i < n; ++i) q2[i] = T1(b_, a_, i);
+        tile_sync();
+        MV_D(sh.D, r1, q0);
+      }
+      BP5_STAMP(1)
+      issue_gather(a, nxt);
+      BP5_STAMP(2)
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const double x0 = q0[i], x1 = q1[i], x2 = q2[i];
+        if constexpr (AFFINE) {
+          const double sc = cur.S[0][i];
+          q0[i] = sc * (cur.Gc[0] * x0 + cur.Gc[3] * x1 + cur.Gc[4] * x2);
+          q1[i] = sc * (cur.Gc[3] * x0 + cur.Gc[1] * x1 + cur.Gc[5] * x2);
+          q2[i] = sc * (cur.Gc[4] * x0 + cur.Gc[5] * x1 + cur.Gc[2] * x2);
+        } else {
+          q0[i] = cur.S[0][i] * x0 + cur.S[3][i] * x1 + cur.S[4][i] * x2;
+          q1[i] = cur.S[3][i] * x0 + cur.S[1][i] * x1 + cur.S[5][i] * x2;
+          q2[i] = cur.S[4][i] * x0 + cur.S[5][i] * x1 + cur.S[2][i] * x2;
+        }
+      }
+      BP5_STAMP(3)
+      double yy[n];
+      if constexpr (!COLL) {
+        double e1[n], e2[n], e3[n], w1[n], w2[n], w3[n];
+        MV_DT(sh.D, q0, e1);
+        MV_NT(sh.N, q1, e2);
+        MV_NT(sh.N, q2, e3);
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e1[i];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) w1[j] = T1(b_, j, a_);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e2[i];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) w2[j] = T1(b_, j, a_);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e3[i];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) w3[j] = T1(b_, j, a_);
+        tile_sync();
+        double f1[n], f2[n], z1[n], z2[n];
+        MV_NT(sh.N, w1, f1);
+        MV_DT_ADD(sh.D, w2, f1);
+        MV_NT(sh.N, w3, f2);
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = f1[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int k = 0; k < n; ++k) z1[k] = T1(k, b_, a_);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = f2[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int k = 0; k < n; ++k) z2[k] = T1(k, b_, a_);
+        tile_sync();
+        MV_NT(sh.N, z1, yy);
+        MV_DT_ADD(sh.D, z2, yy);
+      } else {
+        double e1[n], w1[n], w2[n], z2[n];
+        MV_DT(sh.D, q0, e1);
+        // y-direction: w1 = e1 + D^T q1 (both re-oriented x-owner -> y-owner)
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e1[i];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) w1[j] = T1(b_, j, a_);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) T1(b_, a_, i) = q1[i];
+        }
+        tile_sync();
+#pragma unroll
+        for (int j = 0; j < n; ++j) w2[j] = T1(b_, j, a_);
+        tile_sync();
+        MV_DT_ADD(sh.D, w2, w1);
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < n; ++j) T1(b_, j, a_) = w1[j];
+        }
+        tile_sync();
+#pragma unroll
+        for (int k = 0; k < n; ++k) yy[k] = T1(k, b_, a_);
+        tile_sync();
+        if (act) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) T1(b_, a_, i) = q2[i];
+        }
+        tile_sync();
+#pragma unroll
+        for (int k = 0; k < n; ++k) z2[k] = T1(k, b_, a_);
+        tile_sync();
+        MV_DT_ADD(sh.D, z2, yy);
+      }
+      BP5_STAMP(4)
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        __syncthreads();
+        if (act && cur.round == rd) {
+#pragma unroll
+          for (int k = 0; k < n; ++k) acc[cur.ps[k]] += yy[k];
+        }
+      }
+      BP5_STAMP(5)
+#undef T1
+      return;
+    }
 #define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]
     const bool active = cur.active;
     double(&u)[n] = cur.u;
@@ -1209,7 +1424,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   static_assert(LPC >= n2 && CPT >= 1, "lanes per cell");
   using L = LdsLayout<n, LPC>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *acc = lds + CPT * L::CS; // accumulator behind the transpose tiles
+  double *acc = lds + CPT * BP::TILE_CS; // accumulator behind the transpose tiles
 
   const int t = threadIdx.x;
   const int c = t / LPC, ab = t - c * LPC;
@@ -1229,7 +1444,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   const int abm = ab < n2 ? ab : ab % n2;
   const int slot = c < CPT ? c : 0;
   const int a_ = abm % n, b_ = abm / n;
-  double *T = lds + slot * L::CS;
+  double *T = lds + slot * BP::TILE_CS;
 
   for (int i = t; i < m; i += TEAM) acc[i] = 0.0;
   __syncthreads();

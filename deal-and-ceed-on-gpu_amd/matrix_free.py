@@ -135,6 +135,12 @@ class MatrixFree:
     def set_apply_variant(self, v):
         _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
 
+    def get_apply_variant(self):
+        """The kernel variant a whole-range application resolves to (what 0 = default means here)."""
+        v = C.c_int()
+        _lib.check(_lib.lib().bp5_mf_get_apply_variant(self.handle, C.byref(v)))
+        return v.value
+
     # -- reference API
     def initialize_dof_vector(self, vec=None):
         """== mf_data.initialize_dof_vector(vec), bp5/step-64.cu:214: owned + ghost storage."""

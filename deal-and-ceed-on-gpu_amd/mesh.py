@@ -9,10 +9,10 @@ from . import _lib
 
 
 class BrickMesh:
-    def __init__(self, degree, cells, h=1.0, deform_amp=0.0, rank=0, n_ranks=1, cell_block=(0, 0, 0), dof_numbering=0):
+    def __init__(self, degree, cells, h=1.0, deform_amp=0.0, rank=0, n_ranks=1, cell_block=(0, 0, 0), dof_numbering=0, cell_block_order=0):
         L = _lib.lib()
         d = _lib.MeshDesc(degree, (C.c_uint32 * 3)(*[int(c) for c in cells]), float(h), float(deform_amp), rank, n_ranks,
-                          (C.c_uint32 * 3)(*[int(b) for b in cell_block]), int(dof_numbering))
+                          (C.c_uint32 * 3)(*[int(b) for b in cell_block]), int(dof_numbering), int(cell_block_order))
         self._h = C.c_void_p()
         _lib.check(L.bp5_mesh_create_brick(C.byref(d), C.byref(self._h)))
         v = _lib.MeshView()
@@ -42,6 +42,7 @@ class BrickMesh:
         self.recv_offsets = arr(v.recv_offsets_host, v.n_neighbors + 1, np.uint32)
         self.cell_block = tuple(cell_block)
         self.dof_numbering = dof_numbering
+        self.cell_block_order = cell_block_order
         self.cell_block_offsets = arr(v.cell_block_offsets_host, v.n_cell_blocks + 1, np.uint32) if v.n_cell_blocks else None
 
     def close(self):

@@ -78,6 +78,11 @@ typedef struct {
                              numbered contiguously, then block faces, edges, vertices -- every entity
                              contiguous.  A brick's gather/scatter then touches a few long runs instead
                              of many short rows.  global_ids_host always gives the lexicographic id. */
+  int cell_block_order; /* order of the cells inside a block: 0 lexicographic (x fastest); 1 parity class by
+                             parity class ((x&1, y&1, z&1) relative to the block corner, lexicographic inside a
+                             class): consecutive cells then share no DoF, which is the order the block-assembled
+                             kernel walks them in (its passes read consecutive cells) and spreads the atomics of
+                             the pencil kernel */
 } bp5_mesh_desc;
 
 typedef struct {
@@ -198,8 +203,11 @@ int bp5_copy_constrained(bp5_mf *mf, const double *src, double *dst);
 int bp5_set_constrained(bp5_mf *mf, double value, double *dst);
 
 /* kernel variant selection for the fused operator (tuning / A-B tests):
- * 0 = library default for the degree */
+ * 0 = library default: the measured best kernel for the degree, the geometry mode and the way the
+ * cells were handed over (a mesh given in cell blocks runs the block-assembled kernel at p = 4) */
 int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
+/* the variant a whole-range application resolves to (what "0" means for this handle) */
+int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
 
 /* b_i = int phi_i with Gauss(p+1), constrained rows 0 (assemble_rhs, bp5/step-64.cu:372-418) */
 int bp5_assemble_rhs(bp5_mf *mf, double *b);

@@ -158,6 +158,37 @@ def test_block_major_numbering(p, cells, block, n_ranks):
     assert len(allowned) == o.n_dofs and len(np.unique(allowned)) == o.n_dofs
 
 
+@pytest.mark.parametrize("p,cells,block,n_ranks", [(4, (8, 8, 8), (4, 4, 4), 1), (2, (7, 6, 5), (4, 4, 2), 2), (3, (5, 4, 3), (2, 2, 2), 1)])
+def test_parity_class_cell_order(p, cells, block, n_ranks):
+    """cell_block_order = 1: the same blocks with the same cells as the lexicographic order, but inside a
+    block the cells come parity class by parity class, so the cells of one class (which are consecutive)
+    share no DoF."""
+    for r in range(n_ranks):
+        a = pkg.BrickMesh(p, cells, rank=r, n_ranks=n_ranks, cell_block=block, dof_numbering=1)
+        b = pkg.BrickMesh(p, cells, rank=r, n_ranks=n_ranks, cell_block=block, dof_numbering=1, cell_block_order=1)
+        assert np.array_equal(a.cell_block_offsets, b.cell_block_offsets) and np.array_equal(a.global_ids, b.global_ids)
+        off = a.cell_block_offsets
+        saw_reorder = False
+        for k in range(len(off) - 1):
+            ra = {tuple(row) for row in a.l2g[off[k]:off[k + 1]]}
+            rb = [tuple(row) for row in b.l2g[off[k]:off[k + 1]]]
+            assert ra == set(rb)
+            saw_reorder |= [tuple(row) for row in a.l2g[off[k]:off[k + 1]]] != rb
+            # walk the block: a new class starts whenever the next cell touches a DoF of the running class
+            seen, n_classes = set(), 1
+            for row in rb:
+                if seen & set(row):
+                    n_classes += 1
+                    seen = set()
+                seen |= set(row)
+            assert n_classes <= 8
+        assert saw_reorder == (max(block) > 2)                    # a 2x2x2 block in class order IS lexicographic
+    with pytest.raises(pkg.BP5Error):
+        pkg.BrickMesh(2, (2, 2, 2), cell_block_order=1)            # needs cell_block
+    with pytest.raises(pkg.BP5Error):
+        pkg.BrickMesh(2, (2, 2, 2), cell_block=(2, 2, 2), cell_block_order=2)
+
+
 def test_pure_c_consumer_of_the_abi():
     """include/bp5.h is valid C11 and libbp5.so links from a C program (tests/c/abi_smoke.c)."""
     import subprocess

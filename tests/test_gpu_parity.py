@@ -109,6 +109,43 @@ def test_kernel_variants(p, variant, quad):
     assert rel(dst.cpu().numpy(), ref) < TOL_OP
 
 
+@pytest.mark.parametrize("p,cells,n_ranks,kw,variant", [
+    (4, (5, 4, 7), 2, {}, 0), (4, (5, 4, 7), 3, {}, 10),
+    (4, (5, 4, 9), 2, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 0),
+    (4, (5, 4, 9), 3, dict(cell_block=(4, 4, 2)), 50),
+    (2, (4, 3, 5), 2, {}, 0), (3, (3, 3, 4), 2, {}, 0), (6, (2, 2, 4), 2, {}, 0), (4, (3, 3, 6), 2, {}, 70)])
+def test_rank_local_kernels_with_ghosts(p, cells, n_ranks, kw, variant):
+    """The z-slab meshes of a multi-rank run, one after the other on this one GPU: every rank applies its
+    cells to owned + ghost values and leaves partial sums in owned + ghost entries; summed over the ranks
+    through global_ids they must reproduce the global operator.  (The exchange itself is RCCL and needs
+    one GPU per rank; this covers every kernel family on meshes WITH ghost DoFs, interior cells first.)"""
+    pr = O.Problem(p, cells, 0, deform_amp=0.03, kappa=O.kappa_step64)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=31)
+    ref = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)
+    total = np.zeros_like(ref)
+    for r in range(n_ranks):
+        mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=r, n_ranks=n_ranks, **kw)
+        assert (mesh.n_ghost > 0) == (r > 0)
+        g = mesh.global_ids.astype(np.int64)
+        # the library's step64 coefficient is a function of the physical point, so rank-local == global
+        op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+        op.mf_data.set_apply_variant(variant)
+        if kw.get("cell_block_order") == 1:
+            assert op.mf_data.get_apply_variant() == 56
+        dst = op.initialize_dof_vector()
+        assert dst.numel() == mesh.n_owned + mesh.n_ghost
+        op.mf_data.cell_loop(op.coef, dev(s[g]), dst)
+        np.add.at(total, g, dst.cpu().numpy())
+        if mesh.n_interior_cells < mesh.n_cells:          # the two ranges of an overlapped schedule compose
+            d2 = op.initialize_dof_vector()
+            op.mf_data.set_apply_variant(3 if p == 4 else variant if variant < 50 else 0)
+            op.mf_data.cell_loop(op.coef, dev(s[g]), d2, 0, mesh.n_interior_cells)
+            assert float(d2[mesh.n_owned:].abs().max()) == 0.0      # interior cells touch no ghost
+            op.mf_data.cell_loop(op.coef, dev(s[g]), d2, mesh.n_interior_cells, mesh.n_cells)
+            assert rel(d2.cpu().numpy(), dst.cpu().numpy()) < TOL_OP
+    assert rel(total, ref) < TOL_OP
+
+
 @pytest.mark.parametrize("variant", [0, 3, 10, 11, 50])
 def test_cell_ranges_and_accumulation(variant):
     """cell_loop accumulates (do_zero_out = false semantics) and ranges compose (ranges that cut
@@ -167,7 +204,7 @@ def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
     ref2 = 2 * O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]
     assert rel(acc.cpu().numpy(), ref2) < TOL_OP
     # the other kernels on the permuted numbering
-    for v in (0, 10):
+    for v in (3 if p == 4 else 0, 10):                  # (p = 4: 0 would resolve to the block kernel on this mesh)
         op.mf_data.set_apply_variant(v)
         d3 = op.initialize_dof_vector()
         op.vmult(d3, src)
@@ -182,6 +219,52 @@ def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
         ctl = pkg.IterationNumberControl(6, 0.0)
         solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
         assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+
+
+@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (0, 1), (3, 1)])
+@pytest.mark.parametrize("quad", [0, 1])
+def test_block_kernel_shapes_p4(variant, order, quad):
+    """The other p = 4 block-kernel shapes (32 lanes per cell, single/double buffered, three transpose
+    tiles or one tile used field after field, non-temporal metric loads) on a deformed mesh with partial
+    bricks, cells inside a brick in lexicographic or parity-class order; variant 0 resolves to the block
+    kernel on such a mesh, 3 is the pencil kernel on the same ordering."""
+    torch = _t()
+    p, cells = 4, (9, 6, 5)
+    pr = O.Problem(p, cells, quad, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=order)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
+    op.mf_data.set_apply_variant(variant)
+    s = O.deterministic_src(mesh.n_owned, seed=29)
+    d1 = op.initialize_dof_vector()
+    d1.fill_(float("nan"))
+    op.vmult(d1, dev(s[perm]))
+    assert rel(d1.cpu().numpy(), pr.vmult(s)[perm]) < TOL_OP
+    d2 = op.initialize_dof_vector()
+    op.vmult(d2, dev(s[perm]))
+    if variant != 3:
+        assert torch.equal(d1, d2)                      # block kernels: no atomics, bitwise reproducible
+    assert op.mf_data.get_apply_variant() == (56 if variant == 0 else variant)
+    b = op.assemble_rhs()
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 6)
+    x = op.initialize_dof_vector()
+    pkg.SolverCGFullMerge(pkg.IterationNumberControl(6, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+    assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+
+
+def test_default_variant_resolution():
+    """What variant 0 means: p = 1, 3 team kernel; p = 4: block kernel when the mesh comes in cell blocks
+    that fit, team kernel in affine mode, pencil kernel otherwise; other degrees pencil kernel."""
+    def ev(p, cells, quad=0, geometry=None, **kw):
+        op = pkg.PoissonOperator(pkg.BrickMesh(p, cells, **kw), quad, pkg.COEF_ONE, **({"geometry": geometry} if geometry is not None else {}))
+        return op.mf_data.get_apply_variant()
+    assert ev(4, (4, 4, 4)) == 0
+    assert ev(4, (5, 4, 4), cell_block=(4, 4, 4)) == 56
+    assert ev(4, (5, 4, 4), cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1) == 56
+    assert ev(4, (8, 8, 8), cell_block=(8, 8, 8)) == 0          # 33^3 accumulator does not fit in LDS
+    assert ev(4, (3, 3, 3), geometry=pkg.GEOM_AFFINE) == 10
+    assert ev(3, (3, 3, 3)) == 10 and ev(1, (3, 3, 3)) == 10
+    assert ev(2, (3, 3, 3)) == 0 and ev(5, (2, 2, 2)) == 0 and ev(6, (2, 2, 2), cell_block=(2, 2, 2)) == 0
 
 
 @pytest.mark.parametrize("p", range(1, 9))
@@ -206,7 +289,7 @@ def test_affine_geometry_mode(p, quad):
         assert rel(x.cpu().numpy(), xr) < TOL_CG
 
 
-@pytest.mark.parametrize("variant,block,numbering", [(10, (0, 0, 0), 0), (110, (0, 0, 0), 0), (50, (4, 4, 4), 1), (51, (4, 4, 2), 0), (54, (4, 4, 4), 1), (55, (4, 4, 4), 0)])
+@pytest.mark.parametrize("variant,block,numbering", [(10, (0, 0, 0), 0), (110, (0, 0, 0), 0), (50, (4, 4, 4), 1), (51, (4, 4, 2), 0), (54, (4, 4, 4), 1), (55, (4, 4, 4), 0), (56, (4, 4, 4), 1), (57, (4, 4, 4), 0)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_affine_mode_team_and_block_kernels(variant, block, numbering, quad):
     p, cells = 4, (8, 5, 4)

@@ -19,11 +19,12 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--deform", type=float, default=0.0)
 ap.add_argument("--cell-block", type=int, nargs=3, default=[0, 0, 0])
 ap.add_argument("--numbering", type=int, default=0)
+ap.add_argument("--block-order", type=int, default=0, help="1: parity-class-major cell order inside a block")
 ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6")
 ap.add_argument("--overwrite", action="store_true", help="time vmult with zero_dst=1 instead of the accumulating cell loop")
 a = ap.parse_args()
 p = a.degree
-mesh = pkg.BrickMesh(p, a.cells, h=1.0 / a.cells[0], deform_amp=a.deform, cell_block=a.cell_block, dof_numbering=a.numbering)
+mesh = pkg.BrickMesh(p, a.cells, h=1.0 / a.cells[0], deform_amp=a.deform, cell_block=a.cell_block, dof_numbering=a.numbering, cell_block_order=a.block_order)
 quad = pkg.QUAD_GAUSS if a.quadrature == "gauss" else pkg.QUAD_GLL
 op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE if a.geometry == 'affine' else pkg.GEOM_MERGED6)
 mf = op.mf_data
