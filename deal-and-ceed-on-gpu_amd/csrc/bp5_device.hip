@@ -74,6 +74,7 @@ struct bp5_mf {
   double *h_sc = nullptr; // pinned
   int *h_st = nullptr;    // pinned
   std::vector<hipEvent_t> ev_pool;
+  hipEvent_t prof_mark = nullptr; // profiling: recorded once before the combine pass (= end of the dominant kernel)
   // team plans of the team-assembled kernel, keyed by cells per team
   std::vector<uint32_t> h_l2g;
   struct DevPlan {
@@ -449,6 +450,7 @@ static int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
 static int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
 {
   if (!dp->n_shared) return BP5_OK;
+  if (mf->prof_mark) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
   const dim3 cg((dp->n_shared + 255) / 256);
   if (set) hipLaunchKernelGGL(combine_kernel<false>, cg, dim3(256), 0, mf->stream, dp->sh_dof, dp->sh_off, dp->sh_slot, dp->partial, dst, dp->n_shared);
   else hipLaunchKernelGGL(combine_kernel<true>, cg, dim3(256), 0, mf->stream, dp->sh_dof, dp->sh_off, dp->sh_slot, dp->partial, dst, dp->n_shared);
@@ -1158,24 +1160,17 @@ static int ensure_ws(bp5_mf *mf)
   return BP5_OK;
 }
 
+// four events per profiled application: [0] before the zero-fill, [1] before the cell kernel, [2] after the cell kernel
+// (before the combine pass of the owner-scatter kernels), [3] after everything launch_apply enqueued
 struct ApplyProfile {
   bp5_mf *mf;
   bool on;
   int used = 0;
-  int begin()
+  int mark(int k)
   {
     if (!on) return BP5_OK;
-    if ((size_t)used + 2 > mf->ev_pool.size()) {
-      for (int k = 0; k < 2; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
-    }
-    HIP_TRY(hipEventRecord(mf->ev_pool[used], mf->stream));
-    return BP5_OK;
-  }
-  int end()
-  {
-    if (!on) return BP5_OK;
-    HIP_TRY(hipEventRecord(mf->ev_pool[used + 1], mf->stream));
-    used += 2;
+    while ((size_t)used + 4 > mf->ev_pool.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
+    HIP_TRY(hipEventRecord(mf->ev_pool[used + k], mf->stream));
     return BP5_OK;
   }
 };
@@ -1185,16 +1180,22 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
 {
   const bool dist = mf->comm && mf->comm->n_ranks > 1;
   if (dist) BP5_TRY(bp5_halo_gather(mf, src));
-  // kernels that accumulate with atomics need a zeroed target: do the fill outside the profiled bracket so
-  // that the bracket times the cell kernel alone (owner-scatter kernels define every entry themselves)
+  // kernels that accumulate with atomics need a zeroed target (owner-scatter kernels define every entry themselves)
   const bool owner_scatter = variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells));
+  BP5_TRY(prof.mark(0));
   if (zero && !owner_scatter) {
     HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     zero = false;
   }
-  BP5_TRY(prof.begin());
-  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero));
-  BP5_TRY(prof.end());
+  BP5_TRY(prof.mark(1));
+  if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
+  const int st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero);
+  const bool marked = prof.on && mf->prof_mark == nullptr;
+  mf->prof_mark = nullptr;
+  BP5_TRY(st);
+  if (!marked) BP5_TRY(prof.mark(2));
+  BP5_TRY(prof.mark(3));
+  if (prof.on) prof.used += 4;
   if (dist) { BP5_TRY(bp5_halo_scatter_add(mf, dst)); BP5_TRY(bp5_halo_zero_ghosts(mf, src)); }
   return bp5_copy_constrained(mf, src, dst);
 }
@@ -1305,16 +1306,19 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
   res->residual = mf->h_sc[SC_RES];
   res->initial_residual = mf->h_sc[SC_RES0];
   res->solve_ms = ms;
-  res->apply_ms_avg = 0.0;
-  res->apply_launches = prof.used / 2;
+  res->apply_ms_avg = res->operator_ms_avg = 0.0;
+  res->apply_launches = prof.used / 4;
   if (prof.on && prof.used) {
-    double tot = 0.0;
-    for (int k = 0; k < prof.used; k += 2) {
+    double tot = 0.0, tot_op = 0.0;
+    for (int k = 0; k < prof.used; k += 4) {
       float t = 0.f;
-      HIP_TRY(hipEventElapsedTime(&t, mf->ev_pool[k], mf->ev_pool[k + 1]));
+      HIP_TRY(hipEventElapsedTime(&t, mf->ev_pool[k + 1], mf->ev_pool[k + 2]));
       tot += t;
+      HIP_TRY(hipEventElapsedTime(&t, mf->ev_pool[k], mf->ev_pool[k + 3]));
+      tot_op += t;
     }
-    res->apply_ms_avg = tot / (prof.used / 2);
+    res->apply_ms_avg = tot / (prof.used / 4);
+    res->operator_ms_avg = tot_op / (prof.used / 4);
   }
   if (mf->h_st[ST_BREAKDOWN]) status = fail(BP5_ERR_BREAKDOWN, "CG breakdown: p.Ap is zero or NaN");
   return status;

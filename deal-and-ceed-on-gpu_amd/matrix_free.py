@@ -235,7 +235,7 @@ class SolverControl:
     def __init__(self, max_steps=100, tolerance=1e-10):
         self.max_steps, self.tolerance = int(max_steps), float(tolerance)
         self._last_step, self._last_value, self._initial_value = 0, float("nan"), float("nan")
-        self.solve_ms = self.apply_ms_avg = 0.0
+        self.solve_ms = self.apply_ms_avg = self.operator_ms_avg = 0.0
         self.apply_launches = 0
 
     def last_step(self):
@@ -271,6 +271,7 @@ class _SolverBase:
         c = self.control
         c._last_step, c._last_value, c._initial_value = res.iterations, res.residual, res.initial_residual
         c.solve_ms, c.apply_ms_avg, c.apply_launches = res.solve_ms, res.apply_ms_avg, res.apply_launches
+        c.operator_ms_avg = res.operator_ms_avg
         _lib.check(status)
         return res
 

@@ -262,8 +262,9 @@ typedef struct {
   double residual;         /* last ||r||                                                        */
   double initial_residual;
   double solve_ms;         /* HIP-event time of the whole solve on the stream                   */
-  double apply_ms_avg;     /* profile=1: average duration of one operator launch (cell kernel)  */
+  double apply_ms_avg;     /* profile=1: average duration of one launch of the cell kernel alone  */
   int apply_launches;
+  double operator_ms_avg;  /* profile=1: zero-fill + cell kernel + combine pass (one A*x without halo) */
 } bp5_cg_result;
 
 /* == cg.solve(A, x, b, preconditioner) with DiagonalMatrix (bp5/step-64.cu:446-453,488-495).
