@@ -82,8 +82,8 @@ struct bp5_mf {
     uint16_t *pos = nullptr;
     uint8_t *cell_round = nullptr, *team_rounds = nullptr;
     double *partial = nullptr;
-    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr;
-    uint32_t n_shared = 0, n_groups = 0, max_list = 0;
+    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr;
+    uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
   };
   std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
@@ -214,7 +214,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs};
     for (void *x : pp) if (x) hipFree(x);
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
@@ -428,6 +428,17 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     if (key < 0) {
       BP5_TRY(upload(&dp.pass_cell, h.pass_cell.data(), h.pass_cell.size()));
       BP5_TRY(upload(&dp.pass_off, h.pass_off.data(), h.pass_off.size()));
+      // run-length form of the sorted block lists (consecutive DoFs with equal ownership flag)
+      std::vector<uint32_t> run_off(h.off.size(), 0), runs;
+      for (size_t g = 0; g + 1 < h.off.size(); ++g) {
+        for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i)
+          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1) { runs.push_back(i - h.off[g]); runs.push_back(h.dofs[i]); }
+        run_off[g + 1] = (uint32_t)(runs.size() / 2);
+        dp.max_runs = std::max(dp.max_runs, run_off[g + 1] - run_off[g]);
+      }
+      runs.push_back(0); runs.push_back(0);
+      BP5_TRY(upload(&dp.run_off, run_off.data(), run_off.size()));
+      BP5_TRY(upload(&dp.runs, runs.data(), runs.size()));
     }
     dp.n_shared = (uint32_t)h.sh_dof.size();
     dp.covers_all = h.covers_all;
@@ -470,11 +481,13 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -CPT, &dp));
   const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
-  const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double);
+  const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
+  if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
   BlockPlan bp;
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos;
   bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
+  bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
   // persistent grid: two workgroups per CU (LDS budget), a multiple of 8 for the XCD mapping
   if (!mf->n_cus) {
     hipDeviceProp_t prop;
@@ -541,7 +554,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     fprintf(stderr, "[bp5 stamps] passes/wg %.1f, cycles/pass %.0f\n", tot[8] / n_wg, all / tot[8]);
     for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
   }
-  if (ABL & 1023) return BP5_OK; // timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
+  if (ABL & 1023) return BP5_OK; // (65536 is a real mode too) timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
   return launch_combine(mf, dp, dst, set);
 }
 
@@ -654,7 +667,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     bp5_mf::DevPlan *dp = nullptr;
     mf->auto_block = 0;
     if (get_plan_raw(mf, -8, &dp, 64) == BP5_OK) {
-      const size_t lds = ((size_t)8 * (5 * LdsLayout<5, 32>::PS + 3) + dp->max_list) * sizeof(double);
+      const size_t lds = ((size_t)8 * (5 * LdsLayout<5, 32>::PS + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
       mf->auto_block = lds * 3 <= 160 * 1024;
     }
   }
@@ -664,7 +677,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 static bool variant_overwrites(const bp5_mf *mf, int ev)
 {
   const int v = ev % 100;
-  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 50 && v <= 58)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 50 && v <= 59)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
 }
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
@@ -813,17 +826,29 @@ static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, 
         return st_;
       }
       return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
-    case 456: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
+    case 456: if (c0 == 0 && c1 == mf->n_cells) {
+        bp5_mf::DevPlan *dp_ = nullptr;
+        BP5_TRY(get_plan_raw(mf, -8, &dp_));
+        if (dp_->max_runs <= (uint32_t)BLOCK_MAX_RUNS) // long runs (block-major numbering): write-out without list loads
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite);
+        return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
+      }
       return fail(BP5_ERR_INVALID, "variant 56 needs the whole cell range");
+    case 459: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 59 needs the whole cell range");
     case 457: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 8192>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 57 needs the whole cell range");
     case 458: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 58 needs the whole cell range");
-    case 499: return launch_block_t<4, false, 32, 4096 + 2048 + 8192>(mf, coef, src, dst, true);   // stamps, sequential tiles, 3 WG/CU
+    case 499: return launch_block_t<4, false, 32, 4096 + 2048 + 8192 + 16384>(mf, coef, src, dst, true);   // stamps, sequential tiles, 3 WG/CU, run write-out
     case 452: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
     case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 53 needs the whole cell range");
+    case 487: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 65536>(mf, coef, src, dst, true);  // variant 56 with plain (not non-temporal) stores
+    case 491: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 1>(mf, coef, src, dst, true);  // variant 56 without write-out (and combine)
+    case 493: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 2>(mf, coef, src, dst, true);  // ... without metric loads
+    case 495: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 4>(mf, coef, src, dst, true);  // ... without gather
     case 497: return launch_block_t<4, false, 32, 4096>(mf, coef, src, dst, true);          // stamps, double-buffered
     case 498: return launch_block_t<4, false, 32, 4096 + 2048>(mf, coef, src, dst, true);   // stamps, single-buffered
     case 492: return launch_block_t<4, false, 32, 2049>(mf, coef, src, dst, true);

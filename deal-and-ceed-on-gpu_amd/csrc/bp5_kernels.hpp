@@ -934,6 +934,7 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 // software pipelining instead of occupancy: while pass q computes, the indices, the gathered src
 // values and all six metric planes of pass q+1 are already in flight into a second register set
 // (the kernel may use the full 256 VGPRs at 2 waves per SIMD).
+constexpr int BLOCK_MAX_RUNS = 128;
 struct BlockPlan {
   const uint32_t *pass_cell;  // [n_passes * CPT] cell id per slot; bit 31: idle slot (id still valid)
   const uint32_t *pass_off;   // [n_blocks+1] first pass of each block
@@ -944,6 +945,11 @@ struct BlockPlan {
   const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
   double *partial;            // [off[n_blocks]]
   uint32_t n_blocks, n_wg;    // persistent workgroups, n_wg a multiple of 8
+  // run-length form of dofs (builds with ABL & 16384): run r of block b covers the list slots [runs[2r], runs[2r+2]) and
+  // the consecutive DoFs starting at runs[2r+1] (bit 31 as in dofs); at most BLOCK_MAX_RUNS runs per block
+  const uint32_t *run_off;    // [n_blocks+1]
+  const uint32_t *runs;       // [2 * run_off[n_blocks]]
+  uint32_t max_list;          // longest block list (the accumulator's size in LDS)
   unsigned long long *stamps; // diagnostic builds only: [n_wg][16] cycle sums per phase (never read by kernels)
 };
 
@@ -1440,6 +1446,14 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   uint32_t o0 = bp.off[b];
   int m = (int)(bp.off[b + 1] - o0);
   int n_rounds = bp.blk_rounds[b];
+  // write-out by runs: the block's run table is fetched into registers at the top of its last pass, parked in one of
+  // two LDS tables (block parity: a wave may still be writing out block b while another one enters b + 1) right
+  // before the write-out barrier, and every thread walks it forward for its slots -- no list loads in the write-out
+  constexpr bool RUNS = (ABL & 16384) != 0;
+  uint32_t *const run_tab = reinterpret_cast<uint32_t *>(acc + bp.max_list);
+  uint32_t r0 = RUNS ? bp.run_off[b] : 0u;
+  int n_runs = RUNS ? (int)(bp.run_off[b + 1] - r0) : 0;
+  uint32_t run_slot = 0, run_dof = 0;
   const bool lane_ok = (ab < n2) && (c < CPT);
   const int abm = ab < n2 ? ab : ab % n2;
   const int slot = c < CPT ? c : 0;
@@ -1468,8 +1482,15 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   uint32_t gl[MAXW];
   auto prefetch_list = [&]() {
     if (gp + 1 == boundary) {
+      if constexpr (RUNS) {
+        if (t < n_runs) {
+          run_slot = bp.runs[2 * (r0 + t)];
+          run_dof = bp.runs[2 * (r0 + t) + 1];
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < MAXW; ++r) gl[r] = (t + r * TEAM < m) ? bp.dofs[o0 + t + r * TEAM] : 0u;
+        for (int r = 0; r < MAXW; ++r) gl[r] = (t + r * TEAM < m) ? bp.dofs[o0 + t + r * TEAM] : 0u;
+      }
     }
   };
   auto emit = [&](int i, uint32_t g) {
@@ -1477,18 +1498,36 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     acc[i] = 0.0; // re-arm for the next block (invariant: the accumulator is all zero between blocks)
     if (g & 0x80000000u) {
       if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[g & 0x7fffffffu] = v; }
-      else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
+      else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
+        if constexpr (ABL & 65536) a.dst[g & 0x7fffffffu] = v;
+        else __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
+      }
       else a.dst[g & 0x7fffffffu] += v;
     } else {
       if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
       else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + g, v);
+      else if constexpr (ABL & 65536) bp.partial[o0 + i] = v;
       else __builtin_nontemporal_store(v, bp.partial + o0 + i);
     }
   };
   auto finish_pass = [&]() {
     if (gp + 1 == boundary) {
+      uint32_t *const rt = run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS);
+      if constexpr (RUNS) {
+        if (t < n_runs) {
+          rt[t] = run_slot;
+          rt[BLOCK_MAX_RUNS + t] = run_dof;
+        }
+      }
       __syncthreads(); // every wave has added its last contributions of this block
-      if constexpr (!(ABL & 1)) {
+      if constexpr (RUNS && !(ABL & 1)) {
+        int r = 0;
+        for (int i = t; i < m; i += TEAM) {
+          while (r + 1 < n_runs && (int)rt[r + 1] <= i) ++r;
+          emit(i, rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]));
+        }
+      }
+      if constexpr (!RUNS && !(ABL & 1)) {
 #pragma unroll
         for (int r = 0; r < MAXW; ++r) {
           const int i = t + r * TEAM;
@@ -1509,6 +1548,10 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
         o0 = bp.off[b];
         m = (int)(bp.off[b + 1] - o0);
         n_rounds = bp.blk_rounds[b];
+        if constexpr (RUNS) {
+          r0 = bp.run_off[b];
+          n_runs = (int)(bp.run_off[b + 1] - r0);
+        }
       }
       // no barrier here: the next pass starts with tile work and reaches the accumulation barrier before it
       // touches the accumulator again

@@ -221,7 +221,7 @@ def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
         assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
 
 
-@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (0, 1), (3, 1)])
+@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (59, 1), (0, 1), (3, 1)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_block_kernel_shapes_p4(variant, order, quad):
     """The other p = 4 block-kernel shapes (32 lanes per cell, single/double buffered, three transpose
