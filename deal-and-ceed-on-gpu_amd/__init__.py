@@ -9,9 +9,9 @@ from ._lib import (BP5Error, QUAD_GAUSS, QUAD_GLL, COEF_ONE, COEF_STEP64, CG_PLA
                    lib_path, shape_tables, HEADER_SYMBOLS)
 from .mesh import BrickMesh
 from .matrix_free import (MatrixFree, PoissonOperator, DiagonalMatrix, IterationNumberControl, SolverControl,
-                          SolverCG, SolverCGFullMerge, Communicator)
+                          SolverCG, SolverCGFullMerge, Communicator, Vector)
 
 __all__ = ["BP5Error", "QUAD_GAUSS", "QUAD_GLL", "COEF_ONE", "COEF_STEP64", "CG_PLAIN", "CG_MERGED", "GEOM_MERGED6", "GEOM_AFFINE", "build", "lib",
            "lib_path", "shape_tables", "HEADER_SYMBOLS", "BrickMesh", "MatrixFree", "PoissonOperator",
            "DiagonalMatrix", "IterationNumberControl", "SolverControl", "SolverCG", "SolverCGFullMerge",
-           "Communicator"]
+           "Communicator", "Vector"]

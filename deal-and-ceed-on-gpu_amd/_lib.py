@@ -133,6 +133,8 @@ def lib():
         "bp5_vec_equ": (i32, [vp, vp, f64, vp, sz]),
         "bp5_vec_sadd": (i32, [vp, vp, f64, f64, vp, sz]),
         "bp5_vec_dot": (i32, [vp, vp, vp, sz, C.POINTER(f64)]),
+        "bp5_vec_l2_norm": (i32, [vp, vp, C.c_size_t, C.POINTER(C.c_double)]),
+        "bp5_vec_all_zero": (i32, [vp, vp, C.c_size_t, C.POINTER(C.c_int)]),
         "bp5_comm_unique_id": (i32, [vp]),
         "bp5_comm_create": (i32, [vp, i32, i32, C.POINTER(vp)]),
         "bp5_comm_destroy": (i32, [vp]),

@@ -1028,6 +1028,41 @@ extern "C" int bp5_vec_dot(bp5_mf *mf, const double *x, const double *y, size_t 
   return BP5_OK;
 }
 
+// global reductions of the distributed vector (owned entries of every rank): one on-stream all-reduce when a
+// communicator is attached
+static int reduce_to_host(bp5_mf *mf, int grid, double *result)
+{
+  hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, mf->stream, mf->d_partials, grid, mf->d_scalar, (const int *)nullptr);
+  KERNEL_CHECK();
+  if (mf->comm && mf->comm->n_ranks > 1) NCCL_TRY(ncclAllReduce(mf->d_scalar, mf->d_scalar, 1, ncclDouble, ncclSum, mf->comm->comm, mf->stream));
+  HIP_TRY(hipMemcpyAsync(result, mf->d_scalar, sizeof(double), hipMemcpyDeviceToHost, mf->stream));
+  HIP_TRY(hipStreamSynchronize(mf->stream));
+  return BP5_OK;
+}
+extern "C" int bp5_vec_l2_norm(bp5_mf *mf, const double *x, size_t n, double *result)
+{
+  if (!mf || !x || !result) return fail(BP5_ERR_INVALID, "null argument");
+  if (!aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(mf->device));
+  const int g = stream_grid(n, 2);
+  hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(VB), 0, mf->stream, x, x, n, mf->d_partials);
+  double s = 0.0;
+  BP5_TRY(reduce_to_host(mf, g, &s));
+  *result = sqrt(s);
+  return BP5_OK;
+}
+extern "C" int bp5_vec_all_zero(bp5_mf *mf, const double *x, size_t n, int *result)
+{
+  if (!mf || !x || !result) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  const int g = stream_grid(n, 1);
+  hipLaunchKernelGGL(count_nonzero_kernel, dim3(g), dim3(VB), 0, mf->stream, x, n, mf->d_partials);
+  double s = 0.0;
+  BP5_TRY(reduce_to_host(mf, g, &s));
+  *result = s == 0.0;
+  return BP5_OK;
+}
+
 // ------------------------------------------------------------------------------------ RCCL
 extern "C" int bp5_comm_unique_id(char *id)
 {

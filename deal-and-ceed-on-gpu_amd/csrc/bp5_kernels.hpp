@@ -1915,6 +1915,15 @@ __global__ void __launch_bounds__(VB) dot_kernel(const double *x, const double *
   block_reduce_store<1>(acc, partials);
 }
 
+// number of nonzero (or NaN) entries, as a double so that it travels through the same reduction / all-reduce
+__global__ void __launch_bounds__(VB) count_nonzero_kernel(const double *x, size_t n, double *partials)
+{
+  double acc[1] = {0.0};
+  const size_t stride = (size_t)gridDim.x * VB;
+  for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += stride) acc[0] += (x[i] == 0.0) ? 0.0 : 1.0;
+  block_reduce_store<1>(acc, partials);
+}
+
 // ------------------------------------------------------------------------------------ CG kernels
 // Device-resident solver state.  sc[] doubles, st[] ints.
 enum { SC_GH = 0, SC_DH, SC_GG, SC_GDG, SC_ALPHA, SC_BETA, SC_ALPHA_OLD, SC_BETA_OLD, SC_RES, SC_RES0, SC_TOL, SC_R0 /* 7 merged dots R0..R6 */,

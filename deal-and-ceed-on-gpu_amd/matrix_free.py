@@ -206,6 +206,7 @@ class PoissonOperator:
     def vmult(self, dst, src):
         """dst = [0 +] A src; dst[c] = src[c] on Dirichlet DoFs (bp5/step-64.cu:263-276)."""
         L, mf = _lib.lib(), self.mf_data
+        dst, src = _vals(dst), _vals(src)
         fn = L.bp5_apply_distributed if self.distributed else L.bp5_apply
         _lib.check(fn(mf.handle, _ptr(self.coef), _ptr(src, mf.n_local), _ptr(dst, mf.n_local), 1 if self.do_zero_out else 0))
 
@@ -218,6 +219,83 @@ class PoissonOperator:
         r = C.c_double()
         _lib.check(_lib.lib().bp5_l2_norm_solution(self.mf_data.handle, _ptr(u, self.mf_data.n_local), C.byref(r)))
         return r.value
+
+
+class Vector:
+    """The part of LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA> the reference's path uses
+    (bp5/solver.h:369-382,417-421,511,528; bp5/step-64.cu:349,366-367,431-432,445,449,467), over a torch CUDA
+    tensor (owned entries, then ghosts) and the library's BLAS-1 / halo entry points.  Solvers and operators
+    accept either this class or the bare tensor (`.values`)."""
+
+    def __init__(self, mf=None):
+        self.mf, self.values = mf, None
+        if mf is not None:
+            self.reinit(mf)
+
+    def reinit(self, other, omit_zeroing_entries=False):
+        """reinit(MatrixFree) == initialize_dof_vector; reinit(Vector) == same layout as `other`."""
+        mf = other.mf if isinstance(other, Vector) else other
+        if self.values is None or self.mf is not mf:
+            self.mf = mf
+            self.values = mf.initialize_dof_vector()
+        elif not omit_zeroing_entries:
+            self.assign(0.0)
+        return self
+
+    def assign(self, s):
+        """== operator=(scalar)"""
+        _lib.check(_lib.lib().bp5_vec_fill(self.mf.handle, _ptr(self.values), float(s), self.mf.n_local))
+        return self
+
+    def all_zero(self):
+        z = C.c_int()
+        _lib.check(_lib.lib().bp5_vec_all_zero(self.mf.handle, _ptr(self.values), self.local_size(), C.byref(z)))
+        return bool(z.value)
+
+    def add(self, a, v):
+        _lib.check(_lib.lib().bp5_vec_axpy(self.mf.handle, _ptr(self.values), float(a), _ptr(v.values), self.local_size()))
+
+    def equ(self, a, v):
+        _lib.check(_lib.lib().bp5_vec_equ(self.mf.handle, _ptr(self.values), float(a), _ptr(v.values), self.local_size()))
+
+    def sadd(self, s, a, v):
+        _lib.check(_lib.lib().bp5_vec_sadd(self.mf.handle, _ptr(self.values), float(s), float(a), _ptr(v.values), self.local_size()))
+
+    def l2_norm(self):
+        r = C.c_double()
+        _lib.check(_lib.lib().bp5_vec_l2_norm(self.mf.handle, _ptr(self.values), self.local_size(), C.byref(r)))
+        return r.value
+
+    def get_values(self):
+        return self.values
+
+    def local_size(self):
+        return self.mf.mesh.n_owned
+
+    def size(self):
+        return int(self.mf.mesh.n_global_dofs)
+
+    def import_(self, host_values):
+        """== import(ReadWriteVector, VectorOperation::insert): host values of the owned range."""
+        torch = _torch()
+        h = torch.as_tensor(host_values, dtype=torch.float64)
+        if h.numel() != self.local_size():
+            raise BP5Error(1, "import: need the owned range")
+        self.values[:self.local_size()].copy_(h)
+
+    def update_ghost_values(self):
+        _lib.check(_lib.lib().bp5_halo_gather(self.mf.handle, _ptr(self.values)))
+
+    def compress_add(self):
+        """== compress(VectorOperation::add)"""
+        _lib.check(_lib.lib().bp5_halo_scatter_add(self.mf.handle, _ptr(self.values)))
+
+    def zero_out_ghosts(self):
+        _lib.check(_lib.lib().bp5_halo_zero_ghosts(self.mf.handle, _ptr(self.values)))
+
+
+def _vals(v):
+    return v.values if isinstance(v, Vector) else v
 
 
 class DiagonalMatrix:
@@ -262,7 +340,8 @@ class _SolverBase:
     def solve(self, A, x, b, preconditioner=None):
         """== cg.solve(A, x, b, preconditioner), bp5/step-64.cu:450-453,492-495.  x0 = 0."""
         mf = A.mf_data
-        diag = preconditioner.get_vector() if preconditioner is not None else None
+        x, b = _vals(x), _vals(b)
+        diag = _vals(preconditioner.get_vector()) if preconditioner is not None else None
         prm = _lib.CGParams(self.variant, self.control.max_steps, self.control.tolerance, self.check_every,
                             1 if self.profile else 0)
         res = _lib.CGResult()

@@ -136,6 +136,8 @@ private:
   const double *coef;
 };
 
+using DeviceVector = LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA>; // bp5/step-64.cu:349
+
 // ---- operator wrapper with the reference's public surface (bp5/step-64.cu:198-276)
 template <int dim, int fe_degree>
 class PoissonOperator {
@@ -172,6 +174,8 @@ public:
     mf_data.copy_constrained_values(src, dst);
   }
   void initialize_dof_vector(double **v) const { mf_data.initialize_dof_vector(v); }
+  void initialize_dof_vector(DeviceVector &v) const { mf_data.initialize_dof_vector(v); } // bp5/step-64.cu:214
+  void vmult(DeviceVector &dst, const DeviceVector &src) const { vmult(dst.get_values(), static_cast<const double *>(src.get_values())); }
   bp5_mf *handle() const { return mf_data.handle(); }
   const double *coef() const { return coef_fast; }
   const double *coef_reference_layout() const { return coef_ref; }
@@ -257,6 +261,36 @@ static int run_check(uint32_t nx, uint32_t ny, uint32_t nz, double deform, const
   SolverCGFullMerge cgm(c2);
   cgm.solve(fast, x2, b, DiagonalMatrix());
   const double e_cg = rel_diff(download(x2, n), download(x1, n));
+  // the same solve written against the vector class, as PoissonProblem::solve does (bp5/step-64.cu:428-453,467)
+  double e_vec = 0;
+  {
+    DeviceVector solution, system_rhs, tmp;
+    fast.initialize_dof_vector(solution);
+    fast.initialize_dof_vector(system_rhs);
+    if (!solution.all_zero() || solution.local_size() != n || solution.size() != n) throw std::runtime_error("DeviceVector: reinit/all_zero/size");
+    LinearAlgebra::ReadWriteVector<double> rw(n);
+    const auto hb = download(b, n);
+    for (size_t i = 0; i < n; ++i) rw[i] = hb[i];
+    system_rhs.import(rw, VectorOperation::insert);
+    double nb = 0;
+    for (double v : hb) nb += v * v;
+    if (std::abs(system_rhs.l2_norm() - std::sqrt(nb)) > 1e-13 * std::sqrt(nb) || system_rhs.all_zero()) throw std::runtime_error("DeviceVector: import/l2_norm");
+    IterationNumberControl c3(10, 1e-6 * system_rhs.l2_norm());
+    SolverCGFullMerge cgv(c3);
+    solution = 0;
+    cgv.solve(fast, solution, system_rhs, DiagonalMatrix());
+    e_vec = rel_diff(download(solution.get_values(), n), download(x2, n));
+    // add / equ / sadd / vmult on vectors: tmp = A solution - b, then ||tmp|| = CG residual
+    tmp.reinit(solution);
+    fast.vmult(tmp, solution);
+    tmp.add(-1.0, system_rhs);
+    const double res = tmp.l2_norm();
+    tmp.equ(2.0, system_rhs);
+    tmp.sadd(0.5, -1.0, system_rhs);
+    if (!(tmp.l2_norm() < 1e-14 * system_rhs.l2_norm())) throw std::runtime_error("DeviceVector: equ/sadd");
+    solution.update_ghost_values(); solution.compress(VectorOperation::add); solution.zero_out_ghosts(); // one rank: no-ops
+    printf("vector_api_cg %.3e\nvector_api_residual %.6e\nsolver_residual %.6e\n", e_vec, res, c3.last_value());
+  }
   printf("check p=%d cells=%ux%ux%u dofs=%zu\n", fe_degree, nx, ny, nz, n);
   printf("functor_vs_fused %.3e\nunmerged_vs_fused %.3e\nmetric_functor_vs_library %.3e\nmerged_vs_plain_cg %.3e iterations %u %u\n",
          rel_diff(h2, h1), rel_diff(h3, h1), e_metric, e_cg, c1.last_step(), c2.last_step());

@@ -222,6 +222,10 @@ int bp5_vec_axpy(bp5_mf *mf, double *y, double a, const double *x, size_t n);   
 int bp5_vec_equ(bp5_mf *mf, double *y, double a, const double *x, size_t n);               /* y  = a x   (equ)  */
 int bp5_vec_sadd(bp5_mf *mf, double *y, double s, double a, const double *x, size_t n);    /* y = s y + a x     */
 int bp5_vec_dot(bp5_mf *mf, const double *x, const double *y, size_t n, double *result_host); /* synchronous, local */
+/* Vector::l2_norm() / Vector::all_zero() (bp5/solver.h:369-382, bp5/step-64.cu:467): over the first n (= owned)
+ * entries of every rank -- one on-stream RCCL all-reduce when a communicator is attached; synchronous */
+int bp5_vec_l2_norm(bp5_mf *mf, const double *x, size_t n, double *result_host);
+int bp5_vec_all_zero(bp5_mf *mf, const double *x, size_t n, int *result_host);
 
 /* ------------------------------------------------------------------------------------------ */
 /* communication: one rank per GPU, RCCL over xGMI                                             */

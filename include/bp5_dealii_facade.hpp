@@ -13,7 +13,10 @@
 //         no-argument one, bp5/step-64.cu:190)
 //   CUDAWrappers::SharedData, q_point_id_in_cell, local_q_point_id, get_quadrature_point,
 //   internal::compute_index, block_size, chunk_size, Tensor<1,dim,Number>,
-//   SolverControl / IterationNumberControl / SolverCG / SolverCGFullMerge / DiagonalMatrix.
+//   SolverControl / IterationNumberControl / SolverCG / SolverCGFullMerge / DiagonalMatrix,
+//   LinearAlgebra::distributed::Vector<Number, MemorySpace::CUDA> (the part of its surface the path uses:
+//        reinit, = scalar, all_zero, add, equ, sadd, l2_norm, get_values, local_size, size, import,
+//        update_ghost_values, compress(add), zero_out_ghosts) and LinearAlgebra::ReadWriteVector.
 //
 // This generic path is the functional twin of the reference's apply_kernel_shmem (one thread per
 // local DoF = per q-point, values + gradients[dim] in shared memory, FP64 atomics): it exists for
@@ -152,6 +155,8 @@ public:
   void set_constrained_values(Number val, Number *dst) const { check(bp5_set_constrained(mf, val, dst)); }
   // == initialize_dof_vector(vec): owned + ghost storage
   void initialize_dof_vector(Number **vec) const { check(bp5_vec_alloc(n_local(), vec)); }
+  template <typename VectorType>
+  void initialize_dof_vector(VectorType &vec) const { vec.reinit(mf, n_owned, n_ghost); }
 
 private:
   bp5_mf *mf = nullptr;
@@ -391,6 +396,125 @@ private:
 
 } // namespace CUDAWrappers
 
+// ---- device vector: the part of LinearAlgebra::distributed::Vector<Number, MemorySpace::CUDA> the reference's
+//      path uses (bp5/solver.h:369-382,417-421,511,528; bp5/step-64.cu:349,366-367,431-432,445,449,467).
+//      Storage: owned entries then ghost entries, contiguous (the deal.II layout); global reductions and the
+//      halo calls go through the MatrixFree handle the vector was initialised from.
+namespace MemorySpace {
+struct Host {};
+struct CUDA {};
+} // namespace MemorySpace
+namespace VectorOperation {
+enum values { unknown, insert, add };
+}
+namespace LinearAlgebra {
+template <typename Number>
+class ReadWriteVector { // host staging vector for Vector::import (bp5/step-64.cu:413-416)
+public:
+  ReadWriteVector() = default;
+  explicit ReadWriteVector(size_t n) : v(n, Number(0)) {}
+  void reinit(size_t n) { v.assign(n, Number(0)); }
+  size_t size() const { return v.size(); }
+  Number &operator[](size_t i) { return v[i]; }
+  const Number &operator[](size_t i) const { return v[i]; }
+  Number *data() { return v.data(); }
+  const Number *data() const { return v.data(); }
+
+private:
+  std::vector<Number> v;
+};
+namespace distributed {
+template <typename Number, typename MemorySpaceType = MemorySpace::CUDA>
+class Vector {
+  static_assert(sizeof(Number) == sizeof(double), "the library computes in FP64");
+
+public:
+  using value_type = Number;
+  using size_type = size_t;
+  Vector() = default;
+  Vector(const Vector &) = delete;
+  Vector &operator=(const Vector &) = delete;
+  ~Vector() { if (val) bp5_vec_free(val); }
+
+  // == reinit(locally_owned, ghost, comm): the index sets are those the handle was created with
+  void reinit(bp5_mf *handle, size_t n_owned_, size_t n_ghost_)
+  {
+    if (val) { bp5_vec_free(val); val = nullptr; }
+    mf = handle; n_owned = n_owned_; n_ghost = n_ghost_;
+    check(bp5_vec_alloc(n_owned + n_ghost, &val)); // zero-filled
+  }
+  // == reinit(v, omit_zeroing_entries)
+  void reinit(const Vector &v, bool omit_zeroing_entries = false)
+  {
+    if (!val || n_owned != v.n_owned || n_ghost != v.n_ghost || mf != v.mf) reinit(v.mf, v.n_owned, v.n_ghost);
+    else if (!omit_zeroing_entries) *this = Number(0);
+  }
+  Vector &operator=(Number s)
+  {
+    check(bp5_vec_fill(mf, val, s, n_owned + n_ghost));
+    return *this;
+  }
+  bool all_zero() const
+  {
+    int z = 0;
+    check(bp5_vec_all_zero(mf, val, n_owned, &z));
+    return z != 0;
+  }
+  void add(Number a, const Vector &v) { check(bp5_vec_axpy(mf, val, a, v.val, n_owned)); }
+  void equ(Number a, const Vector &v) { check(bp5_vec_equ(mf, val, a, v.val, n_owned)); }
+  void sadd(Number s, Number a, const Vector &v) { check(bp5_vec_sadd(mf, val, s, a, v.val, n_owned)); }
+  Number l2_norm() const
+  {
+    double r = 0;
+    check(bp5_vec_l2_norm(mf, val, n_owned, &r));
+    return r;
+  }
+  Number *get_values() const { return val; }
+  size_type local_size() const { return n_owned; }
+  size_type n_ghost_entries() const { return n_ghost; }
+  // global size: sum of the owned ranges (one tiny all-reduce, cached)
+  size_type size() const
+  {
+    if (!n_global) {
+      double *tmp = nullptr, h = (double)n_owned;
+      check(bp5_vec_alloc(2, &tmp));
+      check(bp5_copy_h2d(tmp, &h, sizeof(double)));
+      check(bp5_comm_allreduce_sum(mf, tmp, 1));
+      check(bp5_mf_sync(mf));
+      check(bp5_copy_d2h(&h, tmp, sizeof(double)));
+      bp5_vec_free(tmp);
+      n_global = (size_type)(h + 0.5);
+    }
+    return n_global;
+  }
+  // == import(ReadWriteVector, VectorOperation::insert): host values of the owned range
+  void import(const ReadWriteVector<Number> &rw, VectorOperation::values op = VectorOperation::insert)
+  {
+    if (op != VectorOperation::insert || rw.size() != n_owned) throw std::runtime_error("Vector::import: insert of the owned range only");
+    check(bp5_copy_h2d(val, rw.data(), n_owned * sizeof(Number)));
+  }
+  void extract(ReadWriteVector<Number> &rw) const
+  {
+    rw.reinit(n_owned);
+    check(bp5_copy_d2h(rw.data(), val, n_owned * sizeof(Number)));
+  }
+  void update_ghost_values() const { check(bp5_halo_gather(mf, val)); }
+  void compress(VectorOperation::values op)
+  {
+    if (op != VectorOperation::add) throw std::runtime_error("Vector::compress: add only");
+    check(bp5_halo_scatter_add(mf, val));
+  }
+  void zero_out_ghosts() const { check(bp5_halo_zero_ghosts(mf, val)); }
+
+private:
+  bp5_mf *mf = nullptr;
+  Number *val = nullptr;
+  size_t n_owned = 0, n_ghost = 0;
+  mutable size_type n_global = 0;
+};
+} // namespace distributed
+} // namespace LinearAlgebra
+
 // ---- solver-side names (host): thin wrappers over bp5_cg_solve
 class SolverControl {
 public:
@@ -425,6 +549,12 @@ public:
     control.lvalue = res.residual;
     result = res;
     check(s);
+  }
+  // VectorType = LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA> (bp5/step-64.cu:450-453)
+  template <typename MatrixType, typename VectorType>
+  auto solve(const MatrixType &A, VectorType &x, const VectorType &b, const DiagonalMatrix &preconditioner) -> decltype((void)x.get_values())
+  {
+    solve(A, x.get_values(), static_cast<const double *>(b.get_values()), preconditioner);
   }
   bp5_cg_result result{};
 

@@ -26,6 +26,10 @@ def test_facade_functors(tmp_path, p, cells, deform):
     assert vals["unmerged_vs_fused"] < 1e-13           # submit_gradient(get_gradient()) == merged metric
     assert vals["metric_functor_vs_library"] < 1e-13   # evaluate_coefficients(functor) == library metric
     assert vals["merged_vs_plain_cg"] < 1e-11
+    # the same solve through LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA> (reinit, import, l2_norm,
+    # all_zero, add, equ, sadd, = scalar) gives the same iterate; its true residual agrees with the recurrence
+    assert vals["vector_api_cg"] < 1e-14
+    assert abs(vals["vector_api_residual"] - vals["solver_residual"]) < 1e-6 * vals["solver_residual"] + 1e-12
     pr = O.Problem(p, cells, O.QUAD_GAUSS, deform_amp=deform)
     s = np.fromfile(prefix + "_src.bin")
     ref = pr.vmult(s)

@@ -404,7 +404,45 @@ def test_blas1():
         assert np.array_equal(Y.cpu().numpy(), -x)
         L.bp5_vec_fill(h, p(Y), 2.5, n)
         assert np.all(Y.cpu().numpy() == 2.5)
+        L.bp5_vec_l2_norm(h, p(X), n, C.byref(r))
+        assert abs(r.value - np.linalg.norm(x)) < 1e-13 * np.linalg.norm(x)
+        z = C.c_int(-1)
+        L.bp5_vec_all_zero(h, p(X), n, C.byref(z))
+        assert z.value == 0
+        X.zero_()
+        L.bp5_vec_all_zero(h, p(X), n, C.byref(z))
+        assert z.value == 1
+        X[n - 1] = float("nan")                      # a NaN is not zero
+        L.bp5_vec_all_zero(h, p(X), n, C.byref(z))
+        assert z.value == 0
     mf.synchronize()
+
+
+def test_vector_class_mirrors_the_reference_solve():
+    """PoissonProblem::solve written against the Vector class (bp5/step-64.cu:428-453,467): reinit from the
+    operator, = 0, import of host values, l2_norm in the tolerance, all_zero, add/equ/sadd, cg.solve on vectors."""
+    p_, cells = 3, (3, 3, 2)
+    pr = O.Problem(p_, cells, 0, deform_amp=0.02)
+    op = pkg.PoissonOperator(pkg.BrickMesh(p_, cells, deform_amp=0.02), 0, pkg.COEF_ONE)
+    solution, rhs = pkg.Vector(op.mf_data), pkg.Vector(op.mf_data)
+    assert solution.all_zero() and solution.local_size() == pr.mesh.n_dofs == solution.size()
+    rhs.import_(pr.rhs())
+    assert not rhs.all_zero() and abs(rhs.l2_norm() - np.linalg.norm(pr.rhs())) < 1e-13 * np.linalg.norm(pr.rhs())
+    ctl = pkg.IterationNumberControl(9, 1e-6 * rhs.l2_norm())
+    solution.assign(0.0)
+    pkg.SolverCGFullMerge(ctl).solve(op, solution, rhs, pkg.DiagonalMatrix())
+    xr, k, _ = O.cg_plain(pr.vmult, pr.rhs(), 9, tol=1e-6 * np.linalg.norm(pr.rhs()))
+    assert ctl.last_step() == k and rel(solution.values.cpu().numpy(), xr) < TOL_CG
+    tmp = pkg.Vector().reinit(solution)
+    op.vmult(tmp, solution)
+    tmp.add(-1.0, rhs)                                # true residual == recurrence residual
+    assert abs(tmp.l2_norm() - ctl.last_value()) < 1e-9 * rhs.l2_norm()
+    tmp.equ(2.0, rhs)
+    tmp.sadd(0.5, -1.0, rhs)
+    assert tmp.l2_norm() < 1e-14 * rhs.l2_norm()
+    tmp.reinit(solution)                              # same layout: zeroes
+    assert tmp.all_zero()
+    solution.update_ghost_values(); solution.compress_add(); solution.zero_out_ghosts()   # one rank: no-ops
 
 
 # ------------------------------------------------------------------ CG (a12-a14)
