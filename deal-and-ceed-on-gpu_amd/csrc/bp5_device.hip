@@ -952,6 +952,34 @@ extern "C" int bp5_assemble_rhs(bp5_mf *mf, double *b)
   return bp5_set_constrained(mf, 0.0, b);
 }
 template <int n>
+static int launch_diagonal(bp5_mf *mf, const double *coef, double *diag)
+{
+  const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 65536u);
+  const bool affine = mf->geometry_mode == BP5_GEOM_AFFINE;
+  hipLaunchKernelGGL(diagonal_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, affine ? mf->d_scalar_plane : coef,
+                     (uint64_t)mf->n_cells * mf->n3, affine ? mf->d_gcell : (const double *)nullptr, mf->d_tab, mf->n_cells, diag);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+static int diagonal_dispatch(bp5_mf *mf, const double *coef, double *diag) { DISPATCH_N(launch_diagonal, mf, coef, diag); }
+extern "C" int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag, int invert)
+{
+  if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !diag) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  HIP_TRY(hipMemsetAsync(diag, 0, mf->n_local() * sizeof(double), mf->stream));
+  if (mf->n_cells) BP5_TRY(diagonal_dispatch(mf, coef, diag));
+  if (mf->comm && mf->comm->n_ranks > 1) { // ghost contributions to their owners
+    BP5_TRY(bp5_halo_scatter_add(mf, diag));
+    BP5_TRY(bp5_halo_zero_ghosts(mf, diag));
+  }
+  BP5_TRY(bp5_set_constrained(mf, 1.0, diag));                                     // A_eff = P A P + (I - P)
+  if (invert && mf->n_owned) {
+    hipLaunchKernelGGL(reciprocal_kernel, dim3((mf->n_owned + 255) / 256), dim3(256), 0, mf->stream, diag, (size_t)mf->n_owned);
+    KERNEL_CHECK();
+  }
+  return BP5_OK;
+}
+template <int n>
 static int launch_l2(bp5_mf *mf, const double *u, double *out)
 {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 4096u);

@@ -1757,6 +1757,47 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
   }
 }
 
+// diag(A) of the cell loop: diag_ijk += sum_abc S_de(a,b,c) X_de[a,i] Y_de[b,j] Z_de[c,k] with the entrywise products
+// N*N, D*D, N*D as 1-D factors (six transposed tensor contractions per cell).  Setup-time kernel: one block per cell,
+// one thread per local DoF.  coef: the handle's six planes (device layout, q index = a*n*n + b + n*c), or, in affine
+// mode (gcell != NULL), the scalar plane times the cell's constant K K^T.
+template <int n>
+__global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, const double *gcell,
+                                                          const double *tab, uint32_t n_cells, double *diag)
+{
+  constexpr int n2 = n * n, n3 = n2 * n;
+  __shared__ double S[n3], t1[n3], t2[n3], NN[n2], DD[n2], ND[n2];
+  const int i = threadIdx.x, j = threadIdx.y, k = threadIdx.z;
+  const int q = i + n * (j + n * k);
+  if (q < n2) {
+    const double a = tab[q], b = tab[n2 + q];
+    NN[q] = a * a;
+    DD[q] = b * b;
+    ND[q] = a * b;
+  }
+  __syncthreads();
+  for (uint64_t cell = blockIdx.x; cell < n_cells; cell += gridDim.x) {
+    double acc = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      // this thread's q-point (a,b,c) = (i,j,k) sits at i*n2 + j + n*k in the device layout
+      const uint64_t at = cell * n3 + (uint64_t)i * n2 + j + n * k;
+      S[q] = gcell ? coef[at] * gcell[(uint64_t)c * n_cells + cell] : coef[(uint64_t)c * plane_stride + at];
+      __syncthreads();
+      const double *X = (c == 0) ? DD : (c == 3 || c == 4) ? ND : NN;
+      const double *Y = (c == 1) ? DD : (c == 3 || c == 5) ? ND : NN;
+      const double *Z = (c == 2) ? DD : (c == 4 || c == 5) ? ND : NN;
+      const double y = Cell3<n>::template tensor3<true>(X, Y, Z, S, t1, t2, i, j, k);
+      acc += (c < 3) ? y : 2.0 * y;
+    }
+    atomic_add_f64(diag + l2g[cell * n3 + q], acc);
+  }
+}
+__global__ void reciprocal_kernel(double *v, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = 1.0 / v[i];
+}
+
 // sum_cells sum_q (u_h(x_q))^2 JxW  -> *out (atomic)
 template <int n>
 __global__ void __launch_bounds__(n *n *n) l2norm_kernel(const uint32_t *l2g, const double *coords, const double *tab_gauss,

@@ -210,6 +210,13 @@ class PoissonOperator:
         fn = L.bp5_apply_distributed if self.distributed else L.bp5_apply
         _lib.check(fn(mf.handle, _ptr(self.coef), _ptr(src, mf.n_local), _ptr(dst, mf.n_local), 1 if self.do_zero_out else 0))
 
+    def compute_diagonal(self, invert=False):
+        """diag(A_eff) (1 on Dirichlet DoFs) or, with invert=True, the Jacobi preconditioner vector for
+        DiagonalMatrix (the `diag` the reference's solver kernels multiply by, bp5/solver.h:68,100,131,170)."""
+        d = self.initialize_dof_vector()
+        _lib.check(_lib.lib().bp5_compute_diagonal(self.mf_data.handle, _ptr(self.coef), _ptr(d), 1 if invert else 0))
+        return d
+
     def assemble_rhs(self):
         b = self.initialize_dof_vector()
         _lib.check(_lib.lib().bp5_assemble_rhs(self.mf_data.handle, _ptr(b)))

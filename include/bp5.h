@@ -209,6 +209,13 @@ int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
 /* the variant a whole-range application resolves to (what "0" means for this handle) */
 int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
 
+/* diag(A_eff) of the operator bp5_apply applies (1 on Dirichlet DoFs), or its reciprocal when invert != 0: the
+ * Jacobi preconditioner for the `diag` slot every solver kernel of the reference already threads through
+ * (bp5/solver.h:68,100,131,170; bp5/step-64.cu:428-432 fills it with ones).  Setup-time, matrix-free
+ * (sum-factorised, no element matrices); ghost contributions are sent to their owners when a communicator is set.
+ * diag: owned + ghost storage, ghost entries are left zero. */
+int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag, int invert);
+
 /* b_i = int phi_i with Gauss(p+1), constrained rows 0 (assemble_rhs, bp5/step-64.cu:372-418) */
 int bp5_assemble_rhs(bp5_mf *mf, double *b);
 /* ||u_h||_L2 by Gauss(p+1) quadrature (output_results, bp5/step-64.cu:602-616); synchronous */

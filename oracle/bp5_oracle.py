@@ -303,6 +303,27 @@ def element_matrix(coef_cell, N, D):
     return A
 
 
+def operator_diagonal(mesh, coef, N, D, chunk=4096):
+    """diag(A_eff): sum over cells of diag(B^T S B) scattered through l2g, 1 on Dirichlet DoFs
+    (A_eff = P A P + (I - P), Appendix A.4).  The Jacobi preconditioner the reference's solver kernels
+    already thread through as `diag` (bp5/solver.h:68,100,131,170) is its reciprocal.
+    Sum-factorised: diag_ijk = sum_abc S_de(a,b,c) X_de[a,i] Y_de[b,j] Z_de[c,k] with the entrywise
+    products N*N, D*D, N*D as 1-D factors."""
+    n = mesh.n
+    NN, DD, ND = N * N, D * D, N * D
+    fac = [(DD, NN, NN, 1.0), (NN, DD, NN, 1.0), (NN, NN, DD, 1.0), (ND, ND, NN, 2.0), (ND, NN, ND, 2.0), (NN, ND, ND, 2.0)]
+    diag = np.zeros(mesh.n_dofs)
+    for c0 in range(0, mesh.n_cells, chunk):
+        c1 = min(mesh.n_cells, c0 + chunk)
+        S = coef[:, c0:c1].reshape(6, c1 - c0, n, n, n)
+        y = np.zeros((c1 - c0, n, n, n))
+        for c, (X, Y, Z, f) in enumerate(fac):
+            y += f * np.einsum("ck,bj,ai,...cba->...kji", Z, Y, X, S[c], optimize=True)
+        np.add.at(diag, mesh.l2g[c0:c1].astype(np.int64).ravel(), y.reshape(-1))
+    diag[mesh.constrained.astype(np.int64)] = 1.0
+    return diag
+
+
 # ----------------------------------------------------------------------------- RHS (A.6)
 def assemble_rhs(mesh, w_unused=None):
     """b_i = sum_cells sum_q phi_i(x_q) JxW(q) with Gauss(p+1) (bp5/step-64.cu:380,401-405),

@@ -201,3 +201,23 @@ def test_helmholtz_oracle_energy():
     rng = np.random.default_rng(0)
     a, b = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
     assert abs(a @ O.apply_helmholtz_cells(m, N, D, w, b) - b @ O.apply_helmholtz_cells(m, N, D, w, a)) < 1e-11
+
+
+@pytest.mark.parametrize("p,quad,amp", [(1, O.QUAD_GAUSS, 0.0), (2, O.QUAD_GLL, 0.05), (3, O.QUAD_GAUSS, 0.04), (4, O.QUAD_GAUSS, 0.03)])
+def test_operator_diagonal_against_dense_element_matrices_and_unit_vectors(p, quad, amp):
+    """The sum-factorised diagonal equals the diagonal of the assembled dense element matrices and
+    e_i^T A_eff e_i probed through the operator itself."""
+    pr = O.Problem(p, (2, 2, 2) if p > 2 else (3, 2, 2), quad, deform_amp=amp, kappa=O.kappa_step64)
+    d = O.operator_diagonal(pr.mesh, pr.coef, pr.N, pr.D)
+    ref = np.zeros(pr.mesh.n_dofs)
+    for c in range(pr.mesh.n_cells):
+        A = O.element_matrix(pr.coef[:, c], pr.N, pr.D)
+        np.add.at(ref, pr.mesh.l2g[c].astype(np.int64), np.diag(A))
+    ref[pr.mesh.constrained.astype(np.int64)] = 1.0
+    assert np.abs(d - ref).max() < 1e-12 * np.abs(ref).max()
+    rng = np.random.default_rng(3)
+    for i in rng.choice(pr.mesh.n_dofs, 12, replace=False):
+        e = np.zeros(pr.mesh.n_dofs)
+        e[i] = 1.0
+        assert abs(pr.vmult(e)[i] - d[i]) < 1e-12 * abs(d[i])
+    assert (d > 0).all()
