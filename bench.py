@@ -145,6 +145,23 @@ def main():
     n_global = int(mesh.n_global_dofs)
     value = n_global * iters / dt
 
+    # achievable-stream figure: device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
+    import ctypes as C
+    ya, xa = op.initialize_dof_vector(), op.initialize_dof_vector()
+    L, hnd = pkg.lib(), op.mf_data.handle
+    pv = lambda t: C.c_void_p(t.data_ptr())
+    for _ in range(3):
+        L.bp5_vec_equ(hnd, pv(ya), 1.0, pv(xa), mesh.n_owned)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        L.bp5_vec_equ(hnd, pv(ya), 1.0, pv(xa), mesh.n_owned)
+    e1.record()
+    torch.cuda.synchronize()
+    stream_copy_gbs = 16.0 * mesh.n_owned * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del ya, xa
+
     if rank == 0:
         n_cells_local, n_dofs_local = mesh.n_cells, mesh.n_owned
         B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
@@ -164,8 +181,10 @@ def main():
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world}",
                        "cell_block": list(block) if blocked else None, "apply_variant": ev},
+            "value_per_gpu": value / world,   # the reference's convention divides by the rank count (bp5/step-64.cu:457-461)
             "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
-                            "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS},
+                            "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS,
+                            "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": value / world * B / 1e9 / stream_copy_gbs},
             # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs) / average duration of the cell kernel
             # (HIP events on the solver's stream around that launch, inside the timed solve); `operator_ms` is the whole
             # application: zero-fill (atomic kernels) + cell kernel + combine pass (owner-scatter kernels); `traffic`: PMC bytes
