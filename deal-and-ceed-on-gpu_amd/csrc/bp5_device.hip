@@ -47,6 +47,7 @@ struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
+  int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
   int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
   bool force_atomic_scatter = false, block_shared_atomic = false;
@@ -248,6 +249,12 @@ extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
 }
 
 static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1);
+extern "C" int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups)
+{
+  if (!mf || max_workgroups < 0) return fail(BP5_ERR_INVALID, "bad argument");
+  mf->block_max_wg = max_workgroups;
+  return BP5_OK;
+}
 extern "C" int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective)
 {
   if (!mf || !effective) return fail(BP5_ERR_INVALID, "null argument");
@@ -496,6 +503,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   }
   const int wg_per_cu = ((ABL & 2048) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1;
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
+  if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (dp->n_groups + 7) / 8 * 8) / 8 * 8);
   bp.n_wg = n_wg;
   bp.stamps = nullptr;
@@ -669,6 +677,13 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     if (get_plan_raw(mf, -8, &dp, 64) == BP5_OK) {
       const size_t lds = ((size_t)8 * (5 * LdsLayout<5, 32>::PS + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
       mf->auto_block = lds * 3 <= 160 * 1024;
+      // persistent workgroups need enough bricks each to balance (measured: 3.6 bricks per workgroup at 54^3 cells
+      // loses 4 % against the pencil kernel, 32 per workgroup at 116^3 wins): at least 10 per workgroup
+      if (!mf->n_cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
+      }
+      if (dp->n_groups < 30u * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
     }
   }
   return mf->auto_block ? 56 : 0;

@@ -934,6 +934,13 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 // software pipelining instead of occupancy: while pass q computes, the indices, the gathered src
 // values and all six metric planes of pass q+1 are already in flight into a second register set
 // (the kernel may use the full 256 VGPRs at 2 waves per SIMD).
+// Explicit wait for this wave's outstanding LDS operations.  Needed in front of a workgroup barrier that sits at a
+// loop header: the compiler (ROCm 7.2 clang) emits the `s_waitcnt lgkmcnt(0)` of __syncthreads() on the fall-through
+// path only, so an LDS write at the end of the loop body reaches the barrier through the back-edge still in flight,
+// and a wave on another SIMD can pass the barrier and read-modify-write the same word first (lost update; seen as
+// rare wrong sums in multi-round passes at full size).  tools/check_lds_barrier.py checks the ISA for this pattern.
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 constexpr int BLOCK_MAX_RUNS = 128;
 struct BlockPlan {
   const uint32_t *pass_cell;  // [n_passes * CPT] cell id per slot; bit 31: idle slot (id still valid)
@@ -1249,6 +1256,7 @@ struct BlockPass {
       }
       BP5_STAMP(4)
       for (int rd = 0; rd < n_rounds; ++rd) {
+        lds_drain(); // see lds_drain(): the barrier is a loop header
         __syncthreads();
         if (act && cur.round == rd) {
 #pragma unroll
@@ -1402,6 +1410,7 @@ struct BlockPass {
     // pass's (cells of different passes may share DoFs and run on different waves).
     if constexpr (!(ABL & 1)) {
       for (int rd = 0; rd < n_rounds; ++rd) {
+        lds_drain(); // see lds_drain(): the barrier is a loop header
         __syncthreads();
         if (active && cur.round == rd) {
 #pragma unroll
@@ -1460,7 +1469,9 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   const int a_ = abm % n, b_ = abm / n;
   double *T = lds + slot * BP::TILE_CS;
 
-  for (int i = t; i < m; i += TEAM) acc[i] = 0.0;
+  // the whole accumulator, not only this workgroup's first block: a later block of the range may be longer (a
+  // partial brick first, full bricks after it), and write-outs re-arm only the slots they read
+  for (int i = t; i < (int)bp.max_list; i += TEAM) acc[i] = 0.0;
   __syncthreads();
 
   auto entry = [&](uint32_t pass) { return bp.pass_cell[(uint64_t)(pass < gp_end ? pass : gp_end - 1) * CPT + slot]; };

@@ -135,6 +135,9 @@ class MatrixFree:
     def set_apply_variant(self, v):
         _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
 
+    def set_block_workgroups(self, n):
+        _lib.check(_lib.lib().bp5_mf_set_block_workgroups(self.handle, int(n)))
+
     def get_apply_variant(self):
         """The kernel variant a whole-range application resolves to (what 0 = default means here)."""
         v = C.c_int()

@@ -206,6 +206,9 @@ int bp5_set_constrained(bp5_mf *mf, double value, double *dst);
  * 0 = library default: the measured best kernel for the degree, the geometry mode and the way the
  * cells were handed over (a mesh given in cell blocks runs the block-assembled kernel at p = 4) */
 int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
+/* cap on the persistent grid of the block-assembled kernel (0 = sized from the CU count; tuning / tests: a small cap
+ * makes every workgroup walk several blocks even on a small mesh) */
+int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups);
 /* the variant a whole-range application resolves to (what "0" means for this handle) */
 int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
 

@@ -129,9 +129,7 @@ def test_rank_local_kernels_with_ghosts(p, cells, n_ranks, kw, variant):
         g = mesh.global_ids.astype(np.int64)
         # the library's step64 coefficient is a function of the physical point, so rank-local == global
         op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
-        op.mf_data.set_apply_variant(variant)
-        if kw.get("cell_block_order") == 1:
-            assert op.mf_data.get_apply_variant() == 56
+        op.mf_data.set_apply_variant(56 if kw.get("cell_block_order") == 1 else variant)   # (0 picks 56 only on large meshes)
         dst = op.initialize_dof_vector()
         assert dst.numel() == mesh.n_owned + mesh.n_ghost
         op.mf_data.cell_loop(op.coef, dev(s[g]), dst)
@@ -221,13 +219,13 @@ def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
         assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
 
 
-@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (59, 1), (0, 1), (3, 1)])
+@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (59, 1), (3, 1)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_block_kernel_shapes_p4(variant, order, quad):
     """The other p = 4 block-kernel shapes (32 lanes per cell, single/double buffered, three transpose
-    tiles or one tile used field after field, non-temporal metric loads) on a deformed mesh with partial
-    bricks, cells inside a brick in lexicographic or parity-class order; variant 0 resolves to the block
-    kernel on such a mesh, 3 is the pencil kernel on the same ordering."""
+    tiles or one tile used field after field, non-temporal metric loads, list or run-length write-out) on a
+    deformed mesh with partial bricks, cells inside a brick in lexicographic or parity-class order; 3 is the
+    pencil kernel on the same ordering."""
     torch = _t()
     p, cells = 4, (9, 6, 5)
     pr = O.Problem(p, cells, quad, deform_amp=0.03, kappa=O.kappa_step64)
@@ -244,12 +242,44 @@ def test_block_kernel_shapes_p4(variant, order, quad):
     op.vmult(d2, dev(s[perm]))
     if variant != 3:
         assert torch.equal(d1, d2)                      # block kernels: no atomics, bitwise reproducible
-    assert op.mf_data.get_apply_variant() == (56 if variant == 0 else variant)
+    assert op.mf_data.get_apply_variant() == variant
     b = op.assemble_rhs()
     xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 6)
     x = op.initialize_dof_vector()
     pkg.SolverCGFullMerge(pkg.IterationNumberControl(6, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
     assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+
+
+@pytest.mark.parametrize("variant", [50, 52, 56, 59, 57])
+@pytest.mark.parametrize("cells", [(6, 9, 10), (10, 9, 7)])
+def test_block_kernel_persistent_loop_over_unequal_blocks(variant, cells):
+    """A persistent workgroup walks several bricks whose DoF lists differ in length (partial bricks at the
+    mesh edge come first in some ranges): the grid is capped at 8 workgroups so that the small mesh exercises
+    the loop, and a kernel that leaves non-zero LDS behind runs right before (regression: the accumulator
+    was only cleared up to the length of the workgroup's FIRST block)."""
+    p = 4
+    pr = O.Problem(p, cells, 0, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+    assert len(mesh.cell_block_offsets) - 1 >= 18
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    op.mf_data.set_block_workgroups(8)
+    s = O.deterministic_src(mesh.n_owned, seed=41)
+    ref = pr.vmult(s)[perm]
+    refc = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]
+    src = dev(s[perm])
+    for rep in range(3):
+        op.mf_data.set_apply_variant(3)                 # pencil kernel: fills LDS tiles with data
+        scratch = op.initialize_dof_vector()
+        op.vmult(scratch, src)
+        op.mf_data.set_apply_variant(variant)
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        op.vmult(d, src)
+        assert rel(d.cpu().numpy(), ref) < TOL_OP
+        c = op.initialize_dof_vector()
+        op.mf_data.cell_loop(op.coef, src, c)
+        assert rel(c.cpu().numpy(), refc) < TOL_OP
 
 
 def test_default_variant_resolution():
@@ -259,8 +289,8 @@ def test_default_variant_resolution():
         op = pkg.PoissonOperator(pkg.BrickMesh(p, cells, **kw), quad, pkg.COEF_ONE, **({"geometry": geometry} if geometry is not None else {}))
         return op.mf_data.get_apply_variant()
     assert ev(4, (4, 4, 4)) == 0
-    assert ev(4, (5, 4, 4), cell_block=(4, 4, 4)) == 56
-    assert ev(4, (5, 4, 4), cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1) == 56
+    assert ev(4, (5, 4, 4), cell_block=(4, 4, 4)) == 0          # too few bricks per persistent workgroup (see the
+    assert ev(4, (5, 4, 4), cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1) == 0   # full-size test for 56)
     assert ev(4, (8, 8, 8), cell_block=(8, 8, 8)) == 0          # 33^3 accumulator does not fit in LDS
     assert ev(4, (3, 3, 3), geometry=pkg.GEOM_AFFINE) == 10
     assert ev(3, (3, 3, 3)) == 10 and ev(1, (3, 3, 3)) == 10
@@ -596,16 +626,20 @@ def test_medium_size_against_c_oracle():
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("p,cells,quad,amp,km", [(4, (54, 54, 54), 0, 0.0, 1),      # BASELINE config 2
-                                                 (6, (30, 30, 30), 0, 0.05, 0)])     # config 5 shape, reduced
-def test_full_size_properties(p, cells, quad, amp, km):
+@pytest.mark.parametrize("p,cells,quad,amp,km,kw,variant", [
+    (4, (54, 54, 54), 0, 0.0, 1, {}, 0),                                                              # BASELINE config 2
+    (6, (30, 30, 30), 0, 0.05, 0, {}, 0),                                                             # config 5 shape, reduced
+    (4, (86, 84, 82), 0, 0.03, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56)])   # bench mesh order -> block kernel
+def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     """Size-independent properties at BASELINE scale: constants in the null space of the cell
-    loop, symmetry, linearity; CG residual consistency."""
+    loop, symmetry, linearity; CG residual consistency.  The third case is the bench's mesh ordering
+    (bricks, partial bricks at the edges, deformed): the library default must resolve to the block kernel."""
     torch = _t()
     import ctypes as C
-    mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=amp)
+    mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=amp, **kw)
     op = pkg.PoissonOperator(mesh, quad, km)
     mf = op.mf_data
+    assert mf.get_apply_variant() == variant
     n = mesh.n_owned
     L, h = pkg.lib(), mf.handle
     ptr = lambda t: C.c_void_p(t.data_ptr())
@@ -631,6 +665,22 @@ def test_full_size_properties(p, cells, quad, amp, km):
     vAu, uAv = dot(v, Au), dot(u, Av)
     assert abs(vAu - uAv) < 1e-11 * max(abs(vAu), dot(u, Au))
     assert dot(u, Au) > 0
+    if variant == 56:
+        # block kernel at scale, partial bricks (multi-round passes, lists of unequal length in one workgroup's
+        # range): agrees with the atomic pencil kernel and is bitwise reproducible over repeated launches
+        # (regressions: accumulator cleared only up to the first block's length; LDS write in flight at a
+        # loop-header barrier, tests/test_isa_checks.py)
+        mf.set_apply_variant(3)
+        ref = mf.initialize_dof_vector()
+        op.vmult(ref, u)
+        mf.set_apply_variant(0)
+        tol = 1e-12 * float(ref.abs().max())
+        for rep in range(6):
+            d = mf.initialize_dof_vector()
+            d.fill_(float("nan"))
+            op.vmult(d, u)
+            assert bool(((d - ref).abs() < tol).all())
+            assert torch.equal(d, Au)
     w = 2.0 * u - 3.0 * v
     op.vmult(Auv, w)
     lin = 2.0 * Au - 3.0 * Av

@@ -1,0 +1,51 @@
+"""Static checks of the gfx950 ISA the library was built from (no GPU needed).  The device compile keeps its
+assembly (csrc/Makefile, --save-temps); __graft_entry__.build() produces it."""
+import os
+import re
+import sys
+
+import pytest
+
+import bp5_pkg
+
+ISA = os.path.join(bp5_pkg.ROOT, "deal-and-ceed-on-gpu_amd", "csrc", "bp5_device-hip-amdgcn-amd-amdhsa-gfx950.s")
+sys.path.insert(0, os.path.join(bp5_pkg.ROOT, "tools"))
+
+
+def _isa():
+    assert os.path.exists(ISA), "device ISA missing: run __graft_entry__.build() (make -C deal-and-ceed-on-gpu_amd/csrc)"
+    lib = os.path.join(bp5_pkg.ROOT, "deal-and-ceed-on-gpu_amd", "libbp5.so")
+    assert os.path.getmtime(ISA) <= os.path.getmtime(lib) + 1.0, "ISA is newer than libbp5.so: rebuild"
+    return ISA
+
+
+def test_no_barrier_is_reached_with_an_lds_write_in_flight():
+    """Regression for a lost-update race found at full size: clang drops the `s_waitcnt lgkmcnt(0)` of
+    __syncthreads() when the barrier is a loop header and the LDS write comes in through the back-edge (the
+    accumulation rounds of the block kernel).  Every kernel of the library is checked on every path."""
+    import check_lds_barrier
+    assert check_lds_barrier.main(_isa()) == 0
+
+
+def test_checker_detects_the_pattern():
+    """The checker itself: a loop whose body ends in ds_write and whose header is a bare s_barrier is flagged;
+    with the wait in front of the barrier it is not."""
+    import check_lds_barrier
+    bad = ["s_waitcnt lgkmcnt(0)", ".LBB0_1:", "s_barrier", "ds_read_b64 v[0:1], v2", "s_waitcnt lgkmcnt(0)", "ds_write_b64 v2, v[0:1]",
+           "s_cbranch_scc0 .LBB0_1", "s_endpgm"]
+    good = bad[:2] + ["s_waitcnt lgkmcnt(0)"] + bad[2:]
+    assert len(check_lds_barrier.check(bad)) == 1
+    assert check_lds_barrier.check(good) == []
+
+
+def test_default_operator_kernels_do_not_spill():
+    """The p = 4 defaults (block kernel with run-length write-out, pencil kernel) use no scratch and stay within the
+    register budget of three waves per SIMD (168 VGPRs)."""
+    text = open(_isa()).read()
+    want = {"apply_block_kernelILi4ELb0ELi32ELi1ELi26624E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi26624E": 168,
+            "apply_pencil_kernelILi4ELb0ELi4ELi25ELi1ELb1ELi0E": 168}
+    for key, max_vgpr in want.items():
+        m = re.search(r"\.name:\s+_ZN3bp5\d+" + re.escape(key) + r"\w*\n\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n){1,8}?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+        assert m, key
+        assert int(m.group(1)) == 0 and int(m.group(3)) == 0, (key, m.groups())
+        assert int(m.group(2)) <= max_vgpr, (key, m.groups())
