@@ -629,15 +629,21 @@ def test_medium_size_against_c_oracle():
 @pytest.mark.parametrize("p,cells,quad,amp,km,kw,variant", [
     (4, (54, 54, 54), 0, 0.0, 1, {}, 0),                                                              # BASELINE config 2
     (6, (30, 30, 30), 0, 0.05, 0, {}, 0),                                                             # config 5 shape, reduced
-    (4, (86, 84, 82), 0, 0.03, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56)])   # bench mesh order -> block kernel
+    (4, (86, 84, 82), 0, 0.03, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),   # bench mesh order -> block kernel
+    (1, (150, 140, 130), 0, 0.03, 1, {}, 10), (3, (61, 60, 59), 1, 0.03, 1, {}, 10),                  # team-kernel defaults at scale
+    (2, (81, 80, 79), 0, 0.03, 0, {}, 0), (5, (33, 32, 31), 1, 0.03, 1, {}, 0), (7, (23, 22, 21), 0, 0.03, 1, {}, 0),
+    (8, (20, 19, 18), 1, 0.03, 1, {}, 0),
+    (4, (60, 59, 58), 0, 0.0, 1, dict(geometry="affine"), 10), (6, (30, 29, 28), 0, 0.0, 1, dict(geometry="affine"), 0)])
 def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     """Size-independent properties at BASELINE scale: constants in the null space of the cell
     loop, symmetry, linearity; CG residual consistency.  The third case is the bench's mesh ordering
     (bricks, partial bricks at the edges, deformed): the library default must resolve to the block kernel."""
     torch = _t()
     import ctypes as C
+    kw = dict(kw)
+    affine = kw.pop("geometry", None) == "affine"
     mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=amp, **kw)
-    op = pkg.PoissonOperator(mesh, quad, km)
+    op = pkg.PoissonOperator(mesh, quad, km, **({"geometry": pkg.GEOM_AFFINE} if affine else {}))
     mf = op.mf_data
     assert mf.get_apply_variant() == variant
     n = mesh.n_owned
@@ -652,7 +658,7 @@ def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     one = torch.ones(n, dtype=torch.float64, device="cuda:0")
     y = mf.initialize_dof_vector()
     mf.cell_loop(op.coef, one, y)
-    scale = float(torch.abs(op.coef[: mesh.n_cells * (p + 1) ** 3]).max())
+    scale = float(torch.abs(op.coef[: mesh.n_cells * (p + 1) ** 3]).max()) if op.coef is not None else float(1.0 / cells[0])
     assert float(torch.abs(y).max()) < 1e-11 * scale * (p + 1) ** 3
     g = torch.Generator(device="cuda:0").manual_seed(1)
     u = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
@@ -665,12 +671,13 @@ def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     vAu, uAv = dot(v, Au), dot(u, Av)
     assert abs(vAu - uAv) < 1e-11 * max(abs(vAu), dot(u, Au))
     assert dot(u, Au) > 0
-    if variant == 56:
-        # block kernel at scale, partial bricks (multi-round passes, lists of unequal length in one workgroup's
-        # range): agrees with the atomic pencil kernel and is bitwise reproducible over repeated launches
+    if variant != 0:
+        # the non-atomic default kernels at scale (block kernel: partial bricks, multi-round passes, lists of
+        # unequal length in one workgroup's range; team kernel: LDS-staged scatter): entry-wise agreement with the
+        # atomic pencil kernel over repeated launches, bitwise reproducible
         # (regressions: accumulator cleared only up to the first block's length; LDS write in flight at a
         # loop-header barrier, tests/test_isa_checks.py)
-        mf.set_apply_variant(3)
+        mf.set_apply_variant(3 if p == 4 else 1)
         ref = mf.initialize_dof_vector()
         op.vmult(ref, u)
         mf.set_apply_variant(0)
