@@ -111,8 +111,8 @@ def test_kernel_variants(p, variant, quad):
 
 @pytest.mark.parametrize("p,cells,n_ranks,kw,variant", [
     (4, (5, 4, 7), 2, {}, 0), (4, (5, 4, 7), 3, {}, 10),
-    (4, (5, 4, 9), 2, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 0),
-    (4, (5, 4, 9), 3, dict(cell_block=(4, 4, 2)), 50),
+    (4, (9, 10, 17), 2, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 0),
+    (4, (9, 6, 13), 3, dict(cell_block=(4, 4, 2)), 50),
     (2, (4, 3, 5), 2, {}, 0), (3, (3, 3, 4), 2, {}, 0), (6, (2, 2, 4), 2, {}, 0), (4, (3, 3, 6), 2, {}, 70)])
 def test_rank_local_kernels_with_ghosts(p, cells, n_ranks, kw, variant):
     """The z-slab meshes of a multi-rank run, one after the other on this one GPU: every rank applies its
@@ -130,6 +130,7 @@ def test_rank_local_kernels_with_ghosts(p, cells, n_ranks, kw, variant):
         # the library's step64 coefficient is a function of the physical point, so rank-local == global
         op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
         op.mf_data.set_apply_variant(56 if kw.get("cell_block_order") == 1 else variant)   # (0 picks 56 only on large meshes)
+        op.mf_data.set_block_workgroups(8)                # several bricks per persistent workgroup
         dst = op.initialize_dof_vector()
         assert dst.numel() == mesh.n_owned + mesh.n_ghost
         op.mf_data.cell_loop(op.coef, dev(s[g]), dst)
@@ -630,6 +631,7 @@ def test_medium_size_against_c_oracle():
     (4, (54, 54, 54), 0, 0.0, 1, {}, 0),                                                              # BASELINE config 2
     (6, (30, 30, 30), 0, 0.05, 0, {}, 0),                                                             # config 5 shape, reduced
     (4, (86, 84, 82), 0, 0.03, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),   # bench mesh order -> block kernel
+    (4, (116, 116, 116), 0, 0.0, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),  # the bench workload itself (config 3 size on one GPU)
     (1, (150, 140, 130), 0, 0.03, 1, {}, 10), (3, (61, 60, 59), 1, 0.03, 1, {}, 10),                  # team-kernel defaults at scale
     (2, (81, 80, 79), 0, 0.03, 0, {}, 0), (5, (33, 32, 31), 1, 0.03, 1, {}, 0), (7, (23, 22, 21), 0, 0.03, 1, {}, 0),
     (8, (20, 19, 18), 1, 0.03, 1, {}, 0),
