@@ -99,7 +99,8 @@ def _worker(rank, world, port, p, cells, quad, amp, numbering, block, iters, out
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pkg = bp5_pkg.load()
-        m = pkg.BrickMesh(p, cells, deform_amp=amp, rank=rank, n_ranks=world, cell_block=block, dof_numbering=numbering)
+        m = pkg.BrickMesh(p, cells, deform_amp=amp, rank=rank, n_ranks=world, cell_block=block, dof_numbering=numbering,
+                          cell_block_order=1 if (numbering == 1 and block[0] > 2) else 0)
         lm = _LocalMesh(m)
         _, _, w, N, D = O.shape_tables(p, quad)
         coef = O.merged_metric(lm, N, D, w, O.kappa_step64)
@@ -147,7 +148,8 @@ def _worker(rank, world, port, p, cells, quad, amp, numbering, block, iters, out
 
 
 @pytest.mark.parametrize("world,p,cells,numbering,block", [(2, 2, (3, 3, 4), 0, (0, 0, 0)), (2, 3, (4, 3, 5), 1, (2, 2, 2)),
-                                                           (3, 1, (3, 2, 7), 0, (2, 2, 2))])
+                                                           (3, 1, (3, 2, 7), 0, (2, 2, 2)),
+                                                           (2, 4, (5, 4, 6), 1, (4, 4, 4))])   # the bench's ordering (parity-class bricks)
 def test_distributed_cg_matches_single_domain(tmp_path, world, p, cells, numbering, block):
     quad, amp, iters = O.QUAD_GAUSS, 0.03, 8
     port = _free_port()
