@@ -1,0 +1,53 @@
+"""bench.py's one-line JSON contract, on a small workload (child process, one GPU) and through the
+torch.distributed.run launcher with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import bp5_pkg
+
+pytestmark = pytest.mark.gpu
+BENCH = os.path.join(bp5_pkg.ROOT, "bench.py")
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline", "cpu_baseline"}
+
+
+def _check(line, steps, warmup):
+    d = json.loads(line)
+    assert KEYS <= set(d)
+    assert d["unit"] == "DoF/s" and d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["dofs_per_gpu"] * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches"] == steps
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and r["avg_launch_ms"] > 0
+    assert r["operator_ms"] >= r["avg_launch_ms"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "DoF/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    return d
+
+
+def test_bench_json_line_small_workload():
+    r = subprocess.run([sys.executable, BENCH, "--cells", "12", "12", "12", "--steps", "7", "--warmup", "2"], capture_output=True, text=True,
+                       timeout=900, cwd=bp5_pkg.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                              # ONE JSON line
+    d = _check(lines[0], 7, 2)
+    assert d["roofline"]["traffic"] is None             # not the profiled workload
+
+
+def test_bench_under_the_distributed_launcher_one_rank():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", BENCH, "--gpus", "1", "--steps", "4", "--warmup", "1", "--cells", "8", "8", "8",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=bp5_pkg.ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and "cpu_baseline" not in d
