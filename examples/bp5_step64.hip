@@ -149,6 +149,7 @@ public:
     d.n_cells = mv.n_cells; d.n_interior_cells = mv.n_interior_cells; d.n_owned = mv.n_owned; d.n_ghost = mv.n_ghost;
     d.local_to_global_host = mv.local_to_global_host; d.node_coords_host = mv.node_coords_host;
     d.constrained_host = mv.constrained_host; d.n_constrained = mv.n_constrained;
+    d.n_cell_blocks = mv.n_cell_blocks; d.cell_block_offsets_host = mv.cell_block_offsets_host; // cells handed over in bricks (if any)
     mf_data.reinit(d);
     n_owned_cells = mv.n_cells;
     n_local = mv.n_owned + mv.n_ghost;
@@ -309,6 +310,9 @@ static int run_bench(uint32_t ncell, int n_iterations, int n_repetitions)
   constexpr int dim = 3;
   bp5_mesh_desc md{};
   md.degree = fe_degree; md.cells[0] = md.cells[1] = md.cells[2] = ncell; md.h = 1.0 / ncell; md.n_ranks = 1;
+  if (fe_degree == 4) { // the ordering bench.py uses: 4x4x4 bricks, parity-class order inside, brick-major numbering
+    md.cell_block[0] = md.cell_block[1] = md.cell_block[2] = 4; md.dof_numbering = 1; md.cell_block_order = 1;
+  }
   bp5_mesh *mesh;
   check(bp5_mesh_create_brick(&md, &mesh));
   bp5_mesh_view mv;
