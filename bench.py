@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6",
                     help="merged6: the reference's six stored planes per q-point (G=6, default); affine: per-cell metric + one scalar plane (G=1), affine meshes only")
     ap.add_argument("--cell-block", type=int, nargs=3, default=None,
-                    help="hand the cells over in bricks of this many cells (default: 4 4 4 at p=4 -> block-assembled kernel; "
+                    help="hand the cells over in bricks of this many cells (default: 4 4 4 at p=4 -> block-assembled kernel, 8 8 8 at p>=5; "
                          "0 0 0 = lexicographic cell order -> pencil kernel with atomics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -106,7 +106,8 @@ def main():
 
     # cell order / DoF numbering are the host's choice (the reference's MatrixFree::reinit reorders cells too): bricks of
     # 4x4x4 cells, parity-class order inside a brick, brick-major DoF numbering -> the library picks its block kernel
-    block = tuple(args.cell_block) if args.cell_block else ((4, 4, 4) if p == 4 else (0, 0, 0))
+    # (p >= 5: the atomic pencil kernel gains 3-6 % from 8x8x8 parity-class bricks, profiles/r1 g_sweep_order_degrees.txt)
+    block = tuple(args.cell_block) if args.cell_block else ((4, 4, 4) if p == 4 else (8, 8, 8) if p >= 5 else (0, 0, 0))
     blocked = all(b > 0 for b in block)
     mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world,
                          cell_block=block if blocked else (0, 0, 0), dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0)
