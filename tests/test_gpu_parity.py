@@ -730,6 +730,52 @@ def test_single_rank_communicator_and_distributed_entry_points():
     comm.close()
 
 
+@pytest.mark.parametrize("p,cells,seed", [(2, (4, 3, 3), 1), (4, (4, 3, 2), 2), (5, (3, 2, 2), 3)])
+def test_externally_numbered_mesh(p, cells, seed):
+    """nothing in the library assumes the structured generator.  The flat arrays of bp5_mf_desc come
+    from an 'external' mesh here: cells in random order, DoFs in a random numbering, cell groups of random sizes
+    (1..12 cells, not bricks: their cells conflict, so the block kernel needs accumulation rounds) -- every kernel
+    family against the oracle through the permutations."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(seed)
+    pr = O.Problem(p, cells, 0, deform_amp=0.04, kappa=O.kappa_step64)
+    om = pr.mesh
+    n, nc = om.n_dofs, om.n_cells
+    cperm = rng.permutation(nc)                       # new cell k = old cell cperm[k]
+    new_of_old = rng.permutation(n).astype(np.int64)  # DoF numbering: old id -> new id
+    old_of_new = np.argsort(new_of_old)
+    l2g = new_of_old[om.l2g.astype(np.int64)[cperm]].astype(np.uint32)
+    off = [0]
+    while off[-1] < nc:
+        off.append(min(nc, off[-1] + int(rng.integers(1, 13))))
+    mesh = SimpleNamespace(degree=p, n=p + 1, cells=cells, n_cells=nc, n_interior_cells=nc, n_owned=n, n_ghost=0, n_local=n, n_global_dofs=n,
+                           l2g=l2g, coords=np.ascontiguousarray(om.coords[old_of_new]), global_ids=old_of_new.astype(np.uint64),
+                           constrained=np.sort(new_of_old[om.constrained.astype(np.int64)]).astype(np.uint32), n_neighbors=0,
+                           neighbor_rank=np.zeros(0, np.int32), send_offsets=np.zeros(1, np.uint32), send_indices=np.zeros(0, np.uint32),
+                           recv_offsets=np.zeros(1, np.uint32), cell_block_offsets=np.asarray(off, np.uint32), rank=0, n_ranks=1, h=1.0, deform_amp=0.04)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    s = O.deterministic_src(n, seed=seed + 10)        # in the oracle's numbering
+    ref = pr.vmult(s)[old_of_new]
+    src = dev(s[old_of_new])
+    variants = [0, 10, 50] + ([3, 56, 59, 52] if p == 4 else [])
+    for v in variants:
+        op.mf_data.set_apply_variant(v)
+        op.mf_data.set_block_workgroups(8)
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        op.vmult(d, src)
+        assert rel(d.cpu().numpy(), ref) < TOL_OP, v
+    op.mf_data.set_apply_variant(0)
+    assert rel(op.assemble_rhs().cpu().numpy(), pr.rhs()[old_of_new]) < 1e-13
+    assert rel(op.compute_diagonal().cpu().numpy(), O.operator_diagonal(om, pr.coef, pr.N, pr.D)[old_of_new]) < 1e-13
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), 8)
+    for v in ([0, 50] + ([56] if p == 4 else [])):
+        op.mf_data.set_apply_variant(v)
+        x = op.initialize_dof_vector()
+        pkg.SolverCGFullMerge(pkg.IterationNumberControl(8, 0.0)).solve(op, x, op.assemble_rhs(), pkg.DiagonalMatrix())
+        assert rel(x.cpu().numpy(), xr[old_of_new]) < TOL_CG, v
+
+
 # ------------------------------------------------------------------ edge cases
 def test_single_cell_and_tiny_meshes():
     """one cell (every DoF on the Dirichlet boundary except the interior ones), p = 1 and p = 8"""
