@@ -47,6 +47,7 @@ struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
+  uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
   int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
   int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
@@ -495,6 +496,12 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos;
   bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
   bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
+  // a block-aligned cell range: only these blocks run, accumulate mode; DoFs shared with other blocks go to dst by
+  // atomics (the partial slab + combine pass needs every block of the plan in the launch)
+  const bool sub_range = mf->blk_b1 > mf->blk_b0 && (mf->blk_b0 != 0 || mf->blk_b1 != dp->n_groups);
+  bp.blk_begin = sub_range ? mf->blk_b0 : 0;
+  if (sub_range) bp.n_blocks = mf->blk_b1 - mf->blk_b0;
+  if (sub_range && overwrite) return fail(BP5_ERR_INVALID, "a cell range cannot overwrite dst");
   // persistent grid: two workgroups per CU (LDS budget), a multiple of 8 for the XCD mapping
   if (!mf->n_cus) {
     hipDeviceProp_t prop;
@@ -504,7 +511,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const int wg_per_cu = ((ABL & 2048) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1;
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
-  n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (dp->n_groups + 7) / 8 * 8) / 8 * 8);
+  n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
   bp.n_wg = n_wg;
   bp.stamps = nullptr;
   if (ABL & 4096) {
@@ -523,7 +530,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   const dim3 grid(n_wg), block(256);
-  if (mf->block_shared_atomic) {
+  if (mf->block_shared_atomic || sub_range) {
     // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
     if (set && dp->n_shared) {
       hipLaunchKernelGGL(zero_indexed_kernel, dim3((dp->n_shared + 255) / 256), dim3(256), 0, mf->stream, dp->sh_dof, dp->n_shared, dst);
@@ -660,6 +667,17 @@ static int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0
   return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<P, true, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1)
                                         : launch_apply_t<P, false, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1);
 }
+// [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
+static bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1)
+{
+  const auto &o = mf->h_block_off;
+  if (o.empty() || c1 <= c0) return false;
+  const auto i0 = std::lower_bound(o.begin(), o.end(), c0), i1 = std::lower_bound(o.begin(), o.end(), c1);
+  if (i0 == o.end() || i1 == o.end() || *i0 != c0 || *i1 != c1) return false;
+  *b0 = (uint32_t)(i0 - o.begin());
+  *b1 = (uint32_t)(i1 - o.begin());
+  return true;
+}
 // Variant 0 = library default.  The measured choices (profiles/r1): p = 1, 3 x-row team kernel; p = 4 on a mesh
 // handed over in cell blocks that fit three workgroups per CU: block-assembled kernel (no atomics, no zero-fill,
 // bitwise reproducible), whole cell range only; p = 4 affine geometry: team kernel; everything else: pencil kernel.
@@ -670,7 +688,8 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
   if (mf->degree == 1 || mf->degree == 3) return mf->geometry_mode == BP5_GEOM_AFFINE ? 0 : 10;
   if (mf->degree != 4) return 0;
   if (mf->geometry_mode == BP5_GEOM_AFFINE) return 10;
-  if (c0 != 0 || c1 != mf->n_cells || mf->h_block_off.empty()) return 0;
+  uint32_t b0_, b1_;
+  if (mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &b0_, &b1_)) return 0;
   if (mf->auto_block < 0) {
     bp5_mf::DevPlan *dp = nullptr;
     mf->auto_block = 0;
@@ -686,6 +705,8 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
       if (dp->n_groups < 30u * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
     }
   }
+  // sub-ranges: worth it only while the range still feeds the persistent grid (else the pencil kernel)
+  if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (b1_ - b0_) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return 0;
   return mf->auto_block ? 56 : 0;
 }
 // kernels that define every entry of dst themselves (owner stores + combine pass) need no zero-fill
@@ -841,14 +862,15 @@ static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, 
         return st_;
       }
       return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
-    case 456: if (c0 == 0 && c1 == mf->n_cells) {
+    case 456: if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
+        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
         bp5_mf::DevPlan *dp_ = nullptr;
         BP5_TRY(get_plan_raw(mf, -8, &dp_));
         if (dp_->max_runs <= (uint32_t)BLOCK_MAX_RUNS) // long runs (block-major numbering): write-out without list loads
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite);
         return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
       }
-      return fail(BP5_ERR_INVALID, "variant 56 needs the whole cell range");
+      return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
     case 459: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 59 needs the whole cell range");
     case 457: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 8192>(mf, coef, src, dst, overwrite);

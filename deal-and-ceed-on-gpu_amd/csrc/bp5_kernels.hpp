@@ -951,7 +951,8 @@ struct BlockPlan {
   const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
   const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
   double *partial;            // [off[n_blocks]]
-  uint32_t n_blocks, n_wg;    // persistent workgroups, n_wg a multiple of 8
+  uint32_t n_blocks, n_wg;    // blocks of this launch; persistent workgroups, n_wg a multiple of 8
+  uint32_t blk_begin;         // first block of this launch (block-aligned cell ranges; 0 for the whole mesh)
   // run-length form of dofs (builds with ABL & 16384): run r of block b covers the list slots [runs[2r], runs[2r+2]) and
   // the consecutive DoFs starting at runs[2r+1] (bit 31 as in dofs); at most BLOCK_MAX_RUNS runs per block
   const uint32_t *run_off;    // [n_blocks+1]
@@ -1446,8 +1447,8 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   // persistent workgroup w owns the contiguous block range [b0,b1); workgroups that share an XCD
   // (blockIdx % 8, speed only) own neighbouring ranges
   const uint32_t w = (blockIdx.x & 7u) * (bp.n_wg >> 3) + (blockIdx.x >> 3);
-  uint32_t b = (uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg);
-  const uint32_t b1 = (uint32_t)((uint64_t)(w + 1) * bp.n_blocks / bp.n_wg);
+  uint32_t b = bp.blk_begin + (uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg);
+  const uint32_t b1 = bp.blk_begin + (uint32_t)((uint64_t)(w + 1) * bp.n_blocks / bp.n_wg);
   if (b >= b1) return;
   uint32_t gp = bp.pass_off[b];
   const uint32_t gp_end = bp.pass_off[b1];
@@ -1591,7 +1592,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     if (t == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) bp.stamps[(uint64_t)w * 16 + k] = ph[k];
-      bp.stamps[(uint64_t)w * 16 + 8] = gp_end - bp.pass_off[(uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg)];
+      bp.stamps[(uint64_t)w * 16 + 8] = gp_end - bp.pass_off[bp.blk_begin + (uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg)];
     }
   }
 }

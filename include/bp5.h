@@ -197,6 +197,8 @@ int bp5_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, in
  * bp5/step-64.cu:274): cell range [cell_begin, cell_end) only, no zeroing, no Dirichlet copy */
 int bp5_apply_cells(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t cell_begin,
                     uint32_t cell_end);
+/* (with cell blocks: ranges that are unions of whole blocks keep the block-assembled kernel -- DoFs shared with
+ * blocks outside the range are then added atomically; [0, n_interior_cells) of bp5_mesh_create_brick is such a range) */
 /* == mf_data.copy_constrained_values(src, dst), bp5/step-64.cu:275 */
 int bp5_copy_constrained(bp5_mf *mf, const double *src, double *dst);
 /* == MatrixFree::set_constrained_values(val, dst) [upstream] */

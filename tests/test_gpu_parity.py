@@ -283,6 +283,47 @@ def test_block_kernel_persistent_loop_over_unequal_blocks(variant, cells):
         assert rel(c.cpu().numpy(), refc) < TOL_OP
 
 
+@pytest.mark.parametrize("quad", [0, 1])
+def test_block_kernel_on_block_aligned_cell_ranges(quad):
+    """bp5_apply_cells with the block kernel on cell ranges that are unions of whole bricks (what a host that
+    overlaps the halo exchange itself calls: interior bricks, then boundary bricks): the ranges compose to the
+    whole cell loop; DoFs shared with bricks outside the range are added atomically.  Unaligned ranges are
+    refused for the explicit variant."""
+    p, cells = 4, (9, 8, 6)
+    pr = O.Problem(p, cells, quad, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)
+    mf.set_block_workgroups(8)
+    off = mesh.cell_block_offsets
+    s = O.deterministic_src(mesh.n_owned, seed=47)
+    src = dev(s[perm])
+    ref = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]
+    for cuts in ([5], [1, 2, 9], list(range(1, len(off) - 1))):
+        d = mf.initialize_dof_vector()
+        edges = [0] + [int(off[k]) for k in cuts] + [mesh.n_cells]
+        for a, b in zip(edges[:-1], edges[1:]):
+            mf.cell_loop(op.coef, src, d, a, b)
+        assert rel(d.cpu().numpy(), ref) < TOL_OP
+    with pytest.raises(pkg.BP5Error):
+        mf.cell_loop(op.coef, src, mf.initialize_dof_vector(), 0, int(off[1]) + 1)
+    # slab mesh of rank 1 of 2: the interior / boundary split of the overlapped schedule is brick-aligned
+    m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=2, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+    assert m1.n_interior_cells in set(int(x) for x in m1.cell_block_offsets)
+    op1 = pkg.PoissonOperator(m1, quad, pkg.COEF_STEP64)
+    g1 = m1.global_ids.astype(np.int64)
+    whole, split = op1.initialize_dof_vector(), op1.initialize_dof_vector()
+    op1.mf_data.set_apply_variant(3)
+    op1.mf_data.cell_loop(op1.coef, dev(s_ := O.deterministic_src(pr.mesh.n_dofs, seed=48)[g1]), whole)
+    op1.mf_data.set_apply_variant(56)
+    op1.mf_data.cell_loop(op1.coef, dev(s_), split, 0, m1.n_interior_cells)
+    assert float(split[m1.n_owned:].abs().max()) == 0.0
+    op1.mf_data.cell_loop(op1.coef, dev(s_), split, m1.n_interior_cells, m1.n_cells)
+    assert rel(split.cpu().numpy(), whole.cpu().numpy()) < TOL_OP
+
+
 def test_default_variant_resolution():
     """What variant 0 means: p = 1, 3 team kernel; p = 4: block kernel when the mesh comes in cell blocks
     that fit, team kernel in affine mode, pencil kernel otherwise; other degrees pencil kernel."""
