@@ -1364,7 +1364,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
   if (plain) {
     // g = -b, d = -D g, x = 0   (x0 = 0 short-circuit, bp5/solver.h:375-381)
     hipLaunchKernelGGL(cg_init_kernel, dim3(grid1), dim3(VB), 0, s, b, diag, x, g, d, n, mf->d_partials);
-    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(2), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
     KERNEL_CHECK();
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
     hipLaunchKernelGGL(cg_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
@@ -1376,7 +1376,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_DH, 1));
       hipLaunchKernelGGL(cg_update_kernel, dim3(grid2), dim3(VB), 0, s, x, g, d, h, diag, n, mf->d_sc, mf->d_st, mf->d_partials);
-      hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_GG, mf->d_st);
+      hipLaunchKernelGGL(finalize_kernel<2>, dim3(2), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_GG, mf->d_st);
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
       hipLaunchKernelGGL(cg_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
@@ -1390,7 +1390,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
   } else {
     // SolverCGFullMerge: g == r, d == p, h == v
     hipLaunchKernelGGL(cgm_init_kernel, dim3(grid1), dim3(VB), 0, s, b, x, g, d, h, n, mf->d_partials);
-    hipLaunchKernelGGL(finalize_kernel<2>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
+    hipLaunchKernelGGL(finalize_kernel<2>, dim3(2), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
     KERNEL_CHECK();
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
     hipLaunchKernelGGL(cgm_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
@@ -1403,7 +1403,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
       KERNEL_CHECK();
       BP5_TRY(solver_vmult(mf, coef, d, h, true, prof)); // overwrite mode: v needs no zeroing (the reference zeroes it in update_a*)
       hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
-      hipLaunchKernelGGL(finalize_kernel<7>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
+      hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
       hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);

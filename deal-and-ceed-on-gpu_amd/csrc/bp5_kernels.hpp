@@ -1934,13 +1934,13 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[K], double *par
   }
 }
 
-// sums partials[K][nblk] in a fixed tree order into out[K]
+// sums partials[K][nblk] in a fixed tree order into out[K]; one workgroup per value when launched with K blocks
 template <int K>
 __global__ void __launch_bounds__(VB) finalize_kernel(const double *partials, int nblk, double *out, const int *state)
 {
   if (state && state[0]) return;
   __shared__ double red[VB];
-  for (int k = 0; k < K; ++k) {
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
     double s = 0.0;
     for (int i = threadIdx.x; i < nblk; i += VB) s += partials[k * MAXBLK + i];
     red[threadIdx.x] = s;
