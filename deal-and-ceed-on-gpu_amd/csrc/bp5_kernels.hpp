@@ -32,6 +32,34 @@ struct ShapeArg { // passed by value as a kernel argument: uniform -> scalar loa
   double D[n * n];
 };
 
+// ---------------------------------------------------------------------------------- device layout of per-q-point data
+// A cell's n^3 values of one plane (merged metric, affine scalar plane) are consumed in the orientation where lane
+// ab = qj + n qk owns the x-pencil qi = 0..n-1.  "Pair layout": the pencil values are stored as pairs (qi, qi+1), lane
+// after lane, so that a lane fetches 16 bytes per load and a wave's load is one contiguous run (n^2 * 16 bytes per cell);
+// the unpaired last qi of an odd n follows as n^2 single values:
+//   offset(qi, ab) = (qi/2) * 2 n^2 + 2 ab + (qi & 1)      for qi < 2 (n/2)
+//                  = (n/2) * 2 n^2 + ab                     for the last qi of odd n
+// Measured on the block kernel (p = 4): 18 instead of 30 metric load instructions per lane and cell, -4.5 % kernel time.
+template <int n>
+__host__ __device__ constexpr int coef_off(int qi, int ab)
+{
+  return (qi < 2 * (n / 2)) ? (qi / 2) * (2 * n * n) + 2 * ab + (qi & 1) : (n / 2) * (2 * n * n) + ab;
+}
+typedef double bp5_d2u __attribute__((ext_vector_type(2), aligned(8))); // 16-byte load from an 8-byte aligned address
+// the pencil of lane ab from one cell plane (base = plane + cell * n^3)
+template <int n, bool NT = false>
+__device__ __forceinline__ void load_pencil(const double *base, int ab, double (&S)[n])
+{
+#pragma unroll
+  for (int m = 0; m < n / 2; ++m) {
+    const bp5_d2u *q = reinterpret_cast<const bp5_d2u *>(base + m * (2 * n * n) + 2 * ab);
+    const bp5_d2u v = NT ? __builtin_nontemporal_load(q) : *q;
+    S[2 * m] = v.x;
+    S[2 * m + 1] = v.y;
+  }
+  if constexpr (n & 1) S[n - 1] = NT ? __builtin_nontemporal_load(base + (n / 2) * (2 * n * n) + ab) : base[(n / 2) * (2 * n * n) + ab];
+}
+
 struct ApplyArgs {
   const uint32_t *l2g;
   const double *coef;
@@ -158,22 +186,23 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     }
   }
   // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
-  const double *cf = a.coef + cell * n3 + abm;
+  const double *cf = a.coef + cell * n3; // cell base; lane offsets through coef_off / load_pencil
   constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
   double S[(PF && !AFFINE) ? 6 : 1][n];
   double Gc[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (AFFINE) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) S[0][i] = cf[i * n2];
+    load_pencil<n>(cf, abm, S[0]);
 #pragma unroll
     for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
   } else if constexpr (PF) {
 #pragma unroll
-    for (int pl = 0; pl < 6; ++pl)
+    for (int pl = 0; pl < 6; ++pl) {
+      if constexpr (ABL & 2) {
 #pragma unroll
-      for (int i = 0; i < n; ++i)
-        S[pl][i] = (ABL & 2) ? 1.0 + pl + i + 1e-3 * abm
-                             : (ABL & 256) ? __builtin_nontemporal_load(cf + pl * a.plane_stride + i * n2) : cf[pl * a.plane_stride + i * n2];
+        for (int i = 0; i < n; ++i) S[pl][i] = 1.0 + pl + i + 1e-3 * abm;
+      } else
+        load_pencil<n, (ABL & 256) != 0>(cf + pl * a.plane_stride, abm, S[pl]);
+    }
   }
 
   double g0[n], g1[n], g2[n];
@@ -253,12 +282,12 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     } else if constexpr (PF) {
       s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
     } else {
-      s00 = cf[0 * a.plane_stride + i * n2];
-      s11 = cf[1 * a.plane_stride + i * n2];
-      s22 = cf[2 * a.plane_stride + i * n2];
-      s01 = cf[3 * a.plane_stride + i * n2];
-      s02 = cf[4 * a.plane_stride + i * n2];
-      s12 = cf[5 * a.plane_stride + i * n2];
+      s00 = cf[0 * a.plane_stride + coef_off<n>(i, abm)];
+      s11 = cf[1 * a.plane_stride + coef_off<n>(i, abm)];
+      s22 = cf[2 * a.plane_stride + coef_off<n>(i, abm)];
+      s01 = cf[3 * a.plane_stride + coef_off<n>(i, abm)];
+      s02 = cf[4 * a.plane_stride + coef_off<n>(i, abm)];
+      s12 = cf[5 * a.plane_stride + coef_off<n>(i, abm)];
     }
     const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
     g0[i] = s00 * x0 + s01 * x1 + s02 * x2;
@@ -448,22 +477,23 @@ __global__ void __launch_bounds__(64 * TW) apply_march_kernel(ApplyArgs a, March
     }
 
     // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
-    const double *cf = a.coef + cell * n3 + abm;
+    const double *cf = a.coef + cell * n3; // cell base; lane offsets through coef_off / load_pencil
     constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
     double S[(PF && !AFFINE) ? 6 : 1][n];
     double Gc[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (AFFINE) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) S[0][i] = cf[i * n2];
+      load_pencil<n>(cf, abm, S[0]);
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
     } else if constexpr (PF) {
 #pragma unroll
-      for (int pl = 0; pl < 6; ++pl)
+      for (int pl = 0; pl < 6; ++pl) {
+        if constexpr (ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < n; ++i)
-          S[pl][i] = (ABL & 2) ? 1.0 + pl + i + 1e-3 * abm
-                               : (ABL & 256) ? __builtin_nontemporal_load(cf + pl * a.plane_stride + i * n2) : cf[pl * a.plane_stride + i * n2];
+          for (int i = 0; i < n; ++i) S[pl][i] = 1.0 + pl + i + 1e-3 * abm;
+        } else
+          load_pencil<n, (ABL & 256) != 0>(cf + pl * a.plane_stride, abm, S[pl]);
+      }
     }
 
     double g0[n], g1[n], g2[n];
@@ -547,12 +577,12 @@ __global__ void __launch_bounds__(64 * TW) apply_march_kernel(ApplyArgs a, March
       } else if constexpr (PF) {
         s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
       } else {
-        s00 = cf[0 * a.plane_stride + i * n2];
-        s11 = cf[1 * a.plane_stride + i * n2];
-        s22 = cf[2 * a.plane_stride + i * n2];
-        s01 = cf[3 * a.plane_stride + i * n2];
-        s02 = cf[4 * a.plane_stride + i * n2];
-        s12 = cf[5 * a.plane_stride + i * n2];
+        s00 = cf[0 * a.plane_stride + coef_off<n>(i, abm)];
+        s11 = cf[1 * a.plane_stride + coef_off<n>(i, abm)];
+        s22 = cf[2 * a.plane_stride + coef_off<n>(i, abm)];
+        s01 = cf[3 * a.plane_stride + coef_off<n>(i, abm)];
+        s02 = cf[4 * a.plane_stride + coef_off<n>(i, abm)];
+        s12 = cf[5 * a.plane_stride + coef_off<n>(i, abm)];
       }
       const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
       g0[i] = s00 * x0 + s01 * x1 + s02 * x2;
@@ -715,20 +745,17 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
   const int my_round = tp.cell_round[cell];
   const int n_rounds = tp.team_rounds[team];
   // ---- metric planes (issued early; consumed after the evaluate phase)
-  const double *cf = a.coef + cell * n3 + abm;
+  const double *cf = a.coef + cell * n3; // cell base; lane offsets through coef_off / load_pencil
   constexpr bool AFFINE = (ABL & 1024) != 0;
   double S[(PF && !AFFINE) ? 6 : 1][n];
   double Gc[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (AFFINE) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) S[0][i] = cf[i * n2];
+    load_pencil<n>(cf, abm, S[0]);
 #pragma unroll
     for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
   } else if constexpr (PF) {
 #pragma unroll
-    for (int pl = 0; pl < 6; ++pl)
-#pragma unroll
-      for (int i = 0; i < n; ++i) S[pl][i] = cf[pl * a.plane_stride + i * n2];
+    for (int pl = 0; pl < 6; ++pl) load_pencil<n>(cf + pl * a.plane_stride, abm, S[pl]);
   }
   uint16_t ps[n];
   const uint16_t *pos_c = tp.pos + cell * n3 + abm;
@@ -818,8 +845,8 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
     } else if constexpr (PF) {
       s00 = S[0][i]; s11 = S[1][i]; s22 = S[2][i]; s01 = S[3][i]; s02 = S[4][i]; s12 = S[5][i];
     } else {
-      s00 = cf[0 * a.plane_stride + i * n2]; s11 = cf[1 * a.plane_stride + i * n2]; s22 = cf[2 * a.plane_stride + i * n2];
-      s01 = cf[3 * a.plane_stride + i * n2]; s02 = cf[4 * a.plane_stride + i * n2]; s12 = cf[5 * a.plane_stride + i * n2];
+      s00 = cf[0 * a.plane_stride + coef_off<n>(i, abm)]; s11 = cf[1 * a.plane_stride + coef_off<n>(i, abm)]; s22 = cf[2 * a.plane_stride + coef_off<n>(i, abm)];
+      s01 = cf[3 * a.plane_stride + coef_off<n>(i, abm)]; s02 = cf[4 * a.plane_stride + coef_off<n>(i, abm)]; s12 = cf[5 * a.plane_stride + coef_off<n>(i, abm)];
     }
     const double x0 = g0[i], x1 = g1[i], x2 = g2[i];
     g0[i] = s00 * x0 + s01 * x1 + s02 * x2;
@@ -1031,18 +1058,20 @@ struct BlockPass {
   static __device__ __forceinline__ void issue_metric(const ApplyArgs &a, R &r, int abm)
   {
     const uint64_t cell = r.ent & 0x7fffffffu;
-    const double *cf = a.coef + cell * n3 + abm;
+    const double *cf = a.coef + cell * n3; // cell base (pair layout, load_pencil)
     if constexpr (AFFINE) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) r.S[0][i] = cf[i * n2];
+      load_pencil<n>(cf, abm, r.S[0]);
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl) r.Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
     } else {
 #pragma unroll
-      for (int pl = 0; pl < 6; ++pl)
+      for (int pl = 0; pl < 6; ++pl) {
+        if constexpr (ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < n; ++i)
-          r.S[pl][i] = (ABL & 2) ? 1.0 + pl + i : (ABL & 32768) ? __builtin_nontemporal_load(&cf[pl * a.plane_stride + i * n2]) : cf[pl * a.plane_stride + i * n2];
+          for (int i = 0; i < n; ++i) r.S[pl][i] = 1.0 + pl + i;
+        } else
+          load_pencil<n, (ABL & 32768) != 0>(cf + pl * a.plane_stride, abm, r.S[pl]);
+      }
     }
   }
   static __device__ __forceinline__ void issue_gather(const ApplyArgs &a, R &r)
@@ -1690,7 +1719,7 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
     const double jxw = fabs(det) * w[i] * w[j] * w[k];
     if (o.coef) {
       const double s = jxw * kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
-      double *c = o.coef + cell * n3 + (uint64_t)i * n2 + (j + n * k); // permuted: x slowest
+      double *c = o.coef + cell * n3 + coef_off<n>(i, j + n * k); // pair layout (coef_off)
       c[0 * o.plane_stride] = s * (K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2]);
       c[1 * o.plane_stride] = s * (K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2]);
       c[2 * o.plane_stride] = s * (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]);
@@ -1702,7 +1731,7 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
       double Gq[6] = {K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2], K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2],
                       K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2], K[0][0] * K[1][0] + K[0][1] * K[1][1] + K[0][2] * K[1][2],
                       K[0][0] * K[2][0] + K[0][1] * K[2][1] + K[0][2] * K[2][2], K[1][0] * K[2][0] + K[1][1] * K[2][1] + K[1][2] * K[2][2]};
-      o.scalar[cell * n3 + (uint64_t)i * n2 + (j + n * k)] = jxw * kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
+      o.scalar[cell * n3 + coef_off<n>(i, j + n * k)] = jxw * kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
       // reference values of the cell: q-point 0
       for (int c6 = 0; c6 < 6; ++c6) {
         if (q == 0) { t1[c6] = Gq[c6]; o.gcell[(uint64_t)c6 * o.n_cells + cell] = Gq[c6]; }
@@ -1739,7 +1768,7 @@ __global__ void metric_permute_kernel(const double *in, double *out, uint64_t to
     const uint64_t cellplane = o / n3;
     const int q = (int)(o - cellplane * n3); // reference index qi + n(qj + n qk)
     const int qi = q % n, rest = q / n;      // rest = qj + n qk
-    out[o] = in[cellplane * n3 + (uint64_t)qi * n2 + rest];
+    out[o] = in[cellplane * n3 + coef_off<n>(qi, rest)];
   }
 }
 
@@ -1791,8 +1820,8 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
   for (uint64_t cell = blockIdx.x; cell < n_cells; cell += gridDim.x) {
     double acc = 0.0;
     for (int c = 0; c < 6; ++c) {
-      // this thread's q-point (a,b,c) = (i,j,k) sits at i*n2 + j + n*k in the device layout
-      const uint64_t at = cell * n3 + (uint64_t)i * n2 + j + n * k;
+      // this thread's q-point (a,b,c) = (i,j,k) in the device (pair) layout
+      const uint64_t at = cell * n3 + coef_off<n>(i, j + n * k);
       S[q] = gcell ? coef[at] * gcell[(uint64_t)c * n_cells + cell] : coef[(uint64_t)c * plane_stride + at];
       __syncthreads();
       const double *X = (c == 0) ? DD : (c == 3 || c == 4) ? ND : NN;

@@ -158,9 +158,11 @@ int bp5_mf_coef_size(const bp5_mf *mf, size_t *n_doubles);
 
 /* == mf_data.evaluate_coefficients(JacobianFunctor), bp5/step-64.cu:84-114,256-258:
  *    coef_c = kappa * JxW * (K K^T)_c, c in {00,11,22,01,02,12}.
- *    Device layout (this library's own; the reference's is [c][cell][q]):
- *      coef[c*n_cells*nq + cell*nq + qi*n*n + (qj + n*qk)]
- *    i.e. q-points permuted so that the x index is slowest inside a cell. */
+ *    Device layout (this library's own; the reference's is [c][cell][q]; bp5_mf_metric_to_reference_layout converts):
+ *      coef[c*n_cells*nq + cell*nq + off(qi, qj + n*qk)],   n = p+1, nq = n^3, ab = qj + n*qk,
+ *      off(qi, ab) = (qi/2)*2n^2 + 2ab + (qi&1)  for qi < 2(n/2);   (n/2)*2n^2 + ab  for the last qi of odd n
+ *    i.e. per cell the x-pencils of the n^2 (qj,qk) positions, stored as pairs (qi, qi+1) position after position:
+ *    the kernels fetch 16 bytes per lane and a wave's load is one contiguous run. */
 int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef);
 /* Geometry representation used by bp5_apply / bp5_cg_solve:
  *   BP5_GEOM_MERGED6  the reference's six stored planes per q-point (G = 6 doubles per q-point), `coef`
