@@ -84,7 +84,7 @@ struct bp5_mf {
     uint16_t *pos = nullptr;
     uint8_t *cell_round = nullptr, *team_rounds = nullptr;
     double *partial = nullptr;
-    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr;
+    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
   };
@@ -216,7 +216,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx};
     for (void *x : pp) if (x) hipFree(x);
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
@@ -424,7 +424,24 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     bp5_mf::DevPlan dp;
     BP5_TRY(upload(&dp.off, h.off.data(), h.off.size()));
     BP5_TRY(upload(&dp.dofs, h.dofs.data(), h.dofs.size()));
-    BP5_TRY(upload(&dp.pos, h.pos.data(), h.pos.size()));
+    if (key < 0) {
+      // block kernel: per-cell index arrays in the pair layout of the z-pencils (two entries per load, see coef_off)
+      const int n = mf->degree + 1, n2 = n * n;
+      auto off = [&](int k, int ab) { return k < 2 * (n / 2) ? (k / 2) * (2 * n2) + 2 * ab + (k & 1) : (n / 2) * (2 * n2) + ab; };
+      std::vector<uint16_t> pos2(h.pos.size());
+      std::vector<uint32_t> gidx(h.pos.size());
+#pragma omp parallel for schedule(static)
+      for (int64_t c = 0; c < (int64_t)mf->n_cells; ++c)
+        for (int k = 0; k < n; ++k)
+          for (int ab = 0; ab < n2; ++ab) {
+            const size_t from = (size_t)c * mf->n3 + (size_t)k * n2 + ab, to = (size_t)c * mf->n3 + off(k, ab);
+            pos2[to] = h.pos[from];
+            gidx[to] = mf->h_l2g[from];
+          }
+      BP5_TRY(upload(&dp.pos, pos2.data(), pos2.size()));
+      BP5_TRY(upload(&dp.gidx, gidx.data(), gidx.size()));
+    } else
+      BP5_TRY(upload(&dp.pos, h.pos.data(), h.pos.size()));
     BP5_TRY(upload(&dp.cell_round, h.cell_round.data(), h.cell_round.size()));
     BP5_TRY(upload(&dp.team_rounds, h.team_rounds.data(), h.team_rounds.size()));
     BP5_TRY(upload(&dp.sh_dof, h.sh_dof.data(), h.sh_dof.size()));
@@ -493,7 +510,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
   BlockPlan bp;
-  bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos;
+  bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;
   bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
   bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
   // a block-aligned cell range: only these blocks run, accumulate mode; DoFs shared with other blocks go to dst by

@@ -961,6 +961,20 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 // software pipelining instead of occupancy: while pass q computes, the indices, the gathered src
 // values and all six metric planes of pass q+1 are already in flight into a second register set
 // (the kernel may use the full 256 VGPRs at 2 waves per SIMD).
+// the same pair layout for the block plan's per-cell index arrays (z-pencil of lane ab = i + n j, entries k = 0..n-1)
+template <int n, typename T>
+__device__ __forceinline__ void load_pencil_idx(const T *base, int ab, T (&v)[n])
+{
+  typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+#pragma unroll
+  for (int m = 0; m < n / 2; ++m) {
+    const pair_t q = *reinterpret_cast<const pair_t *>(base + m * (2 * n * n) + 2 * ab);
+    v[2 * m] = q.x;
+    v[2 * m + 1] = q.y;
+  }
+  if constexpr (n & 1) v[n - 1] = base[(n / 2) * (2 * n * n) + ab];
+}
+
 // Explicit wait for this wave's outstanding LDS operations.  Needed in front of a workgroup barrier that sits at a
 // loop header: the compiler (ROCm 7.2 clang) emits the `s_waitcnt lgkmcnt(0)` of __syncthreads() on the fall-through
 // path only, so an LDS write at the end of the loop body reaches the barrier through the back-edge still in flight,
@@ -974,7 +988,8 @@ struct BlockPlan {
   const uint32_t *pass_off;   // [n_blocks+1] first pass of each block
   const uint32_t *off;        // [n_blocks+1] offsets into dofs / partial
   const uint32_t *dofs;       // sorted distinct DoFs per block; bit 31: touched by this block only
-  const uint16_t *pos;        // [n_cells*n^3] position of each local DoF in its block's list
+  const uint16_t *pos;        // [n_cells*n^3] position of each local DoF in its block's list, pair layout (coef_off(k, i + n j))
+  const uint32_t *gidx;       // [n_cells*n^3] local_to_global in the same pair layout
   const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
   const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
   double *partial;            // [off[n_blocks]]
@@ -1046,12 +1061,8 @@ struct BlockPass {
   {
     r.active = lane_ok && exists && !(r.ent >> 31);
     const uint64_t cell = r.ent & 0x7fffffffu;
-    const uint32_t *l2g_c = a.l2g + cell * n3 + abm;
-    const uint16_t *pos_c = bp.pos + cell * n3 + abm;
-#pragma unroll
-    for (int k = 0; k < n; ++k) r.idx[k] = l2g_c[k * n2];
-#pragma unroll
-    for (int k = 0; k < n; ++k) r.ps[k] = pos_c[k * n2];
+    load_pencil_idx<n, uint32_t>(bp.gidx + cell * n3, abm, r.idx);
+    load_pencil_idx<n, uint16_t>(bp.pos + cell * n3, abm, r.ps);
     r.round = bp.cell_round[cell];
     if constexpr (!SINGLE) issue_metric(a, r, abm);
   }
@@ -1551,6 +1562,28 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       else __builtin_nontemporal_store(v, bp.partial + o0 + i);
     }
   };
+  // two consecutive list slots of one run: 16-byte LDS read, 16-byte global store (half the store instructions)
+  auto emit2 = [&](int i, uint32_t g) {
+    const double v0 = acc[i], v1 = acc[i + 1];
+    acc[i] = 0.0;
+    acc[i + 1] = 0.0;
+    if (g & 0x80000000u) {
+      double *d = a.dst + (g & 0x7fffffffu);
+      if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
+        if constexpr (ABL & 65536) { d[0] = v0; d[1] = v1; }
+        else __builtin_nontemporal_store(bp5_d2u{v0, v1}, reinterpret_cast<bp5_d2u *>(d));
+      } else {
+        const bp5_d2u o = *reinterpret_cast<const bp5_d2u *>(d);
+        *reinterpret_cast<bp5_d2u *>(d) = bp5_d2u{o.x + v0, o.y + v1};
+      }
+    } else {
+      if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) {
+        atomic_add_f64(a.dst + g, v0);
+        atomic_add_f64(a.dst + g + 1, v1);
+      } else if constexpr (ABL & 65536) { bp.partial[o0 + i] = v0; bp.partial[o0 + i + 1] = v1; }
+      else __builtin_nontemporal_store(bp5_d2u{v0, v1}, reinterpret_cast<bp5_d2u *>(bp.partial + o0 + i));
+    }
+  };
   auto finish_pass = [&]() {
     if (gp + 1 == boundary) {
       uint32_t *const rt = run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS);
@@ -1562,10 +1595,17 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       }
       __syncthreads(); // every wave has added its last contributions of this block
       if constexpr (RUNS && !(ABL & 1)) {
+        // thread t takes the slot pairs (2t, 2t+1) + 2 TEAM j: a pair inside one run goes out as 16 bytes
         int r = 0;
-        for (int i = t; i < m; i += TEAM) {
+        for (int i = 2 * t; i < m; i += 2 * TEAM) {
           while (r + 1 < n_runs && (int)rt[r + 1] <= i) ++r;
-          emit(i, rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]));
+          const uint32_t g = rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]);
+          const bool run_ends = r + 1 < n_runs && (int)rt[r + 1] == i + 1;
+          if (i + 1 < m && !run_ends) emit2(i, g);
+          else {
+            emit(i, g);
+            if (i + 1 < m) emit(i + 1, rt[BLOCK_MAX_RUNS + r + 1]); // first slot of the next run
+          }
         }
       }
       if constexpr (!RUNS && !(ABL & 1)) {
