@@ -98,7 +98,8 @@ def main():
         comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
 
     p = args.degree
-    n1 = {1: 367, 2: 184, 3: 122, 4: 116, 5: 92, 6: 73, 7: 61, 8: 52}[p] if p != 4 else 116
+    # p = 4: the headline size (config 3: 116^3 cells, 100 544 625 DoFs); other degrees: config 4 (~5e7 DoFs)
+    n1 = {1: 367, 2: 184, 3: 122, 4: 116, 5: 73, 6: 61, 7: 52, 8: 46}[p]
     cells_per_gpu = tuple(args.cells) if args.cells else (n1, n1, n1)
     cells = (cells_per_gpu[0], cells_per_gpu[1], cells_per_gpu[2] * world)  # weak scaling: z-slabs
     quad = pkg.QUAD_GAUSS if args.quadrature == "gauss" else pkg.QUAD_GLL
