@@ -85,6 +85,7 @@ struct bp5_mf {
     uint8_t *cell_round = nullptr, *team_rounds = nullptr;
     double *partial = nullptr;
     uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
+    uint16_t *packed = nullptr;
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
   };
@@ -216,7 +217,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed};
     for (void *x : pp) if (x) hipFree(x);
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
@@ -391,7 +392,7 @@ static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   constexpr int n = P + 1;
   constexpr int CPT = 64 * TW / LPC;
   using L = LdsLayout<n, LPC>;
-  ApplyArgs a;
+  ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = c0; a.cell_end = c1;
@@ -424,22 +425,56 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     bp5_mf::DevPlan dp;
     BP5_TRY(upload(&dp.off, h.off.data(), h.off.size()));
     BP5_TRY(upload(&dp.dofs, h.dofs.data(), h.dofs.size()));
+    std::vector<uint32_t> run_off, runs;
     if (key < 0) {
+      // run-length form of the sorted block lists: consecutive DoFs with equal ownership flag, cut at 2048 entries so
+      // that (run, offset) packs into 5 + 11 bits
+      run_off.assign(h.off.size(), 0);
+      for (size_t g = 0; g + 1 < h.off.size(); ++g) {
+        uint32_t start = h.off[g];
+        for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i)
+          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1 || i - start == 2048) {
+            start = i;
+            runs.push_back(i - h.off[g]);
+            runs.push_back(h.dofs[i]);
+          }
+        run_off[g + 1] = (uint32_t)(runs.size() / 2);
+        dp.max_runs = std::max(dp.max_runs, run_off[g + 1] - run_off[g]);
+      }
       // block kernel: per-cell index arrays in the pair layout of the z-pencils (two entries per load, see coef_off)
       const int n = mf->degree + 1, n2 = n * n;
       auto off = [&](int k, int ab) { return k < 2 * (n / 2) ? (k / 2) * (2 * n2) + 2 * ab + (k & 1) : (n / 2) * (2 * n2) + ab; };
-      std::vector<uint16_t> pos2(h.pos.size());
+      std::vector<uint16_t> pos2(h.pos.size()), packed(dp.max_runs <= 32 ? h.pos.size() : 0);
       std::vector<uint32_t> gidx(h.pos.size());
-#pragma omp parallel for schedule(static)
-      for (int64_t c = 0; c < (int64_t)mf->n_cells; ++c)
-        for (int k = 0; k < n; ++k)
-          for (int ab = 0; ab < n2; ++ab) {
-            const size_t from = (size_t)c * mf->n3 + (size_t)k * n2 + ab, to = (size_t)c * mf->n3 + off(k, ab);
-            pos2[to] = h.pos[from];
-            gidx[to] = mf->h_l2g[from];
+#pragma omp parallel
+      {
+        std::vector<uint16_t> run_of_slot;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t g = 0; g < (int64_t)h.group_cell_off.size() - 1; ++g) {
+          const uint32_t nr = run_off[g + 1] - run_off[g], m = h.off[g + 1] - h.off[g];
+          if (!packed.empty()) {
+            run_of_slot.assign(m, 0);
+            for (uint32_t r = 0; r < nr; ++r) {
+              const uint32_t s0 = runs[2 * (run_off[g] + r)], s1 = r + 1 < nr ? runs[2 * (run_off[g] + r + 1)] : m;
+              for (uint32_t sl = s0; sl < s1; ++sl) run_of_slot[sl] = (uint16_t)r;
+            }
           }
+          for (size_t c = h.group_cell_off[g]; c < h.group_cell_off[g + 1]; ++c)
+            for (int k = 0; k < n; ++k)
+              for (int ab = 0; ab < n2; ++ab) {
+                const size_t from = c * mf->n3 + (size_t)k * n2 + ab, to = c * mf->n3 + off(k, ab);
+                pos2[to] = h.pos[from];
+                gidx[to] = mf->h_l2g[from];
+                if (!packed.empty()) {
+                  const uint32_t sl = h.pos[from], r = run_of_slot[sl];
+                  packed[to] = (uint16_t)(r << 11 | (sl - runs[2 * (run_off[g] + r)]));
+                }
+              }
+        }
+      }
       BP5_TRY(upload(&dp.pos, pos2.data(), pos2.size()));
       BP5_TRY(upload(&dp.gidx, gidx.data(), gidx.size()));
+      if (!packed.empty()) BP5_TRY(upload(&dp.packed, packed.data(), packed.size()));
     } else
       BP5_TRY(upload(&dp.pos, h.pos.data(), h.pos.size()));
     BP5_TRY(upload(&dp.cell_round, h.cell_round.data(), h.cell_round.size()));
@@ -453,14 +488,6 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     if (key < 0) {
       BP5_TRY(upload(&dp.pass_cell, h.pass_cell.data(), h.pass_cell.size()));
       BP5_TRY(upload(&dp.pass_off, h.pass_off.data(), h.pass_off.size()));
-      // run-length form of the sorted block lists (consecutive DoFs with equal ownership flag)
-      std::vector<uint32_t> run_off(h.off.size(), 0), runs;
-      for (size_t g = 0; g + 1 < h.off.size(); ++g) {
-        for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i)
-          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1) { runs.push_back(i - h.off[g]); runs.push_back(h.dofs[i]); }
-        run_off[g + 1] = (uint32_t)(runs.size() / 2);
-        dp.max_runs = std::max(dp.max_runs, run_off[g + 1] - run_off[g]);
-      }
       runs.push_back(0); runs.push_back(0);
       BP5_TRY(upload(&dp.run_off, run_off.data(), run_off.size()));
       BP5_TRY(upload(&dp.runs, runs.data(), runs.size()));
@@ -508,9 +535,11 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
   const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
+  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 32 runs per block: packed indices unavailable");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
-  BlockPlan bp;
+  BlockPlan bp{}; // value-initialised: a field this launcher forgets is null, not garbage
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;
+  bp.packed = dp->packed;
   bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
   bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
   // a block-aligned cell range: only these blocks run, accumulate mode; DoFs shared with other blocks go to dst by
@@ -536,7 +565,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipMemsetAsync(mf->d_stamps, 0, 4096 * 16 * sizeof(unsigned long long), mf->stream));
     bp.stamps = mf->d_stamps;
   }
-  ApplyArgs a;
+  ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
@@ -597,10 +626,10 @@ static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
   constexpr int n = P + 1;
   constexpr int CPT = 64 * TW / LPC;
   using L = LdsLayout<n, LPC>;
-  TeamPlan tp;
+  TeamPlan tp{};
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan(mf, CPT, tp, &dp));
-  ApplyArgs a;
+  ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = c0; a.cell_end = c1;
@@ -649,10 +678,10 @@ static int launch_march_t(bp5_mf *mf, const double *coef, const double *src, dou
     dm.n_teams = (uint32_t)h.team_off.size() - 1;
     it = mf->march_plans.emplace(CPT, dm).first;
   }
-  MarchPlan mp;
+  MarchPlan mp{};
   mp.team_off = it->second.team_off; mp.entries = it->second.entries; mp.n_teams = it->second.n_teams;
   mp.teams_per_xcd = (mp.n_teams + 7) / 8;
-  ApplyArgs a;
+  ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = mp.n_teams; a.teams_per_xcd = mp.teams_per_xcd;
@@ -730,7 +759,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 static bool variant_overwrites(const bp5_mf *mf, int ev)
 {
   const int v = ev % 100;
-  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 50 && v <= 59)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 49 && v <= 59)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
 }
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
@@ -879,11 +908,15 @@ static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, 
         return st_;
       }
       return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
+    case 449: // = 56 with run-length write-out but without packed indices (A/B)
     case 456: if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
         struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
         bp5_mf::DevPlan *dp_ = nullptr;
         BP5_TRY(get_plan_raw(mf, -8, &dp_));
-        if (dp_->max_runs <= (uint32_t)BLOCK_MAX_RUNS) // long runs (block-major numbering): write-out without list loads
+        if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);
+        if (dp_->max_runs <= (uint32_t)BLOCK_MAX_RUNS) // write-out without list loads
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite);
         return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
       }

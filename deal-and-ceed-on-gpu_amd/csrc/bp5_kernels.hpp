@@ -990,6 +990,10 @@ struct BlockPlan {
   const uint32_t *dofs;       // sorted distinct DoFs per block; bit 31: touched by this block only
   const uint16_t *pos;        // [n_cells*n^3] position of each local DoF in its block's list, pair layout (coef_off(k, i + n j))
   const uint32_t *gidx;       // [n_cells*n^3] local_to_global in the same pair layout
+  // packed form (builds with ABL & 262144): ONE u16 per cell-local DoF = run << 11 | offset in the run (runs are cut at
+  // 2048 entries, at most 32 per block); list slot = run_slot[run] + offset, DoF = run_dof[run] + offset, both from the
+  // block's run table in LDS -- the local_to_global stream is not read at all
+  const uint16_t *packed;     // [n_cells*n^3], pair layout
   const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
   const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
   double *partial;            // [off[n_blocks]]
@@ -1047,6 +1051,7 @@ struct BlockPass {
   static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
   // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
   // workgroup needs a third of the tile memory: 4x4x4 accumulator + tiles = 47 KB -> three workgroups per CU
+  static constexpr bool PACK = (ABL & 262144) != 0; // packed (run, offset) indices, decoded through the LDS run table
   static constexpr bool SEQ = (ABL & 8192) != 0;
   static_assert(!SEQ || WAVE_LOCAL, "sequential tiles need wave-local cells");
   static constexpr int TILE_CS = SEQ ? (n * L::PS + 3) : L::CS; // doubles per cell slot
@@ -1061,8 +1066,11 @@ struct BlockPass {
   {
     r.active = lane_ok && exists && !(r.ent >> 31);
     const uint64_t cell = r.ent & 0x7fffffffu;
-    load_pencil_idx<n, uint32_t>(bp.gidx + cell * n3, abm, r.idx);
-    load_pencil_idx<n, uint16_t>(bp.pos + cell * n3, abm, r.ps);
+    if constexpr (PACK) load_pencil_idx<n, uint16_t>(bp.packed + cell * n3, abm, r.ps); // decoded by decode_and_gather
+    else {
+      load_pencil_idx<n, uint32_t>(bp.gidx + cell * n3, abm, r.idx);
+      load_pencil_idx<n, uint16_t>(bp.pos + cell * n3, abm, r.ps);
+    }
     r.round = bp.cell_round[cell];
     if constexpr (!SINGLE) issue_metric(a, r, abm);
   }
@@ -1083,6 +1091,18 @@ struct BlockPass {
         } else
           load_pencil<n, (ABL & 32768) != 0>(cf + pl * a.plane_stride, abm, r.S[pl]);
       }
+    }
+  }
+  // PACK: r.ps holds the packed entries of the pass; turn them into list slots (kept in r.ps for the accumulation) and
+  // DoF indices through the run table `rt` of the pass's block, and start the gather
+  static __device__ __forceinline__ void decode_and_gather(const ApplyArgs &a, R &r, const uint32_t *rt)
+  {
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      const uint32_t e = r.ps[k], run = e >> 11, off = e & 2047u;
+      const uint32_t dof = (rt[BLOCK_MAX_RUNS + run] & 0x7fffffffu) + off;
+      r.ps[k] = (uint16_t)(rt[run] + off);
+      r.u[k] = (ABL & 4) ? 1e-9 * dof : a.src[dof];
     }
   }
   static __device__ __forceinline__ void issue_gather(const ApplyArgs &a, R &r)
@@ -1187,7 +1207,7 @@ struct BlockPass {
         MV_D(sh.D, r1, q0);
       }
       BP5_STAMP(1)
-      issue_gather(a, nxt);
+      if constexpr (!PACK) issue_gather(a, nxt); // PACK: after the pass, once the next block's run table is parked
       BP5_STAMP(2)
 #pragma unroll
       for (int i = 0; i < n; ++i) {
@@ -1368,7 +1388,7 @@ struct BlockPass {
 
     BP5_STAMP(1) // evaluate (z/y/x contractions; its first use of u waits for the gather)
     // the index loads of the next pass have landed by now: start its src gather
-    issue_gather(a, nxt);
+    if constexpr (!PACK) issue_gather(a, nxt);
     BP5_STAMP(2) // wait for the next pass's indices + issue of its gather
 
 #pragma unroll
@@ -1525,7 +1545,17 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   A.ent = entry(gp);
   B.ent = entry(gp + 1);
   BP::issue_loads(a, bp, A, abm, lane_ok, true);
-  BP::issue_gather(a, A);
+  if constexpr (BP::PACK) {
+    // the first block's run table must be in LDS before the first decode
+    uint32_t *const rt0 = run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS);
+    if (t < n_runs) {
+      rt0[t] = bp.runs[2 * (r0 + t)];
+      rt0[BLOCK_MAX_RUNS + t] = bp.runs[2 * (r0 + t) + 1];
+    }
+    __syncthreads();
+    BP::decode_and_gather(a, A, rt0);
+  } else
+    BP::issue_gather(a, A);
 
   // end-of-pass bookkeeping: when a block is finished, write it out and re-arm the accumulator.  The block's
   // DoF list is prefetched into registers at the top of its last pass (prefetch_list), so the write-out does
@@ -1534,7 +1564,16 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   uint32_t gl[MAXW];
   auto prefetch_list = [&]() {
     if (gp + 1 == boundary) {
-      if constexpr (RUNS) {
+      if constexpr (BP::PACK) {
+        // table of the NEXT block (this block's own table has been in LDS since the end of the previous block)
+        if (b + 1 < b1) {
+          const uint32_t rn = bp.run_off[b + 1];
+          if (t < (int)(bp.run_off[b + 2] - rn)) {
+            run_slot = bp.runs[2 * (rn + t)];
+            run_dof = bp.runs[2 * (rn + t) + 1];
+          }
+        }
+      } else if constexpr (RUNS) {
         if (t < n_runs) {
           run_slot = bp.runs[2 * (r0 + t)];
           run_dof = bp.runs[2 * (r0 + t) + 1];
@@ -1587,7 +1626,17 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   auto finish_pass = [&]() {
     if (gp + 1 == boundary) {
       uint32_t *const rt = run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS);
-      if constexpr (RUNS) {
+      if constexpr (BP::PACK) {
+        // park the next block's table in the other buffer: its last readers (block b - 1) finished before this
+        // block's first accumulation barrier
+        if (b + 1 < b1) {
+          uint32_t *const rn = run_tab + ((b + 1) & 1u) * (2 * BLOCK_MAX_RUNS);
+          if (t < (int)(bp.run_off[b + 2] - bp.run_off[b + 1])) {
+            rn[t] = run_slot;
+            rn[BLOCK_MAX_RUNS + t] = run_dof;
+          }
+        }
+      } else if constexpr (RUNS) {
         if (t < n_runs) {
           rt[t] = run_slot;
           rt[BLOCK_MAX_RUNS + t] = run_dof;
@@ -1648,6 +1697,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     finish_pass();
     BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
+    if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS)); // b: block of the next pass
     A.ent = entA2;
     prefetch_list();
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
@@ -1655,6 +1705,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev);
     finish_pass();
     BP5_STAMP(6)
+    if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS)); }
     B.ent = entB2;
   }
   if constexpr (ABL & 4096) {

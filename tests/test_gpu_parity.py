@@ -220,7 +220,7 @@ def test_block_kernel_on_blocked_mesh(p, cells, block, quad, numbering):
         assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
 
 
-@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (59, 1), (3, 1)])
+@pytest.mark.parametrize("variant,order", [(52, 0), (53, 1), (56, 0), (56, 1), (57, 1), (58, 1), (59, 1), (49, 1), (3, 1)])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_block_kernel_shapes_p4(variant, order, quad):
     """The other p = 4 block-kernel shapes (32 lanes per cell, single/double buffered, three transpose
@@ -251,7 +251,7 @@ def test_block_kernel_shapes_p4(variant, order, quad):
     assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
 
 
-@pytest.mark.parametrize("variant", [50, 52, 56, 59, 57])
+@pytest.mark.parametrize("variant", [50, 52, 56, 49, 59, 57])
 @pytest.mark.parametrize("cells", [(6, 9, 10), (10, 9, 7)])
 def test_block_kernel_persistent_loop_over_unequal_blocks(variant, cells):
     """A persistent workgroup walks several bricks whose DoF lists differ in length (partial bricks at the
@@ -798,7 +798,7 @@ def test_externally_numbered_mesh(p, cells, seed):
     s = O.deterministic_src(n, seed=seed + 10)        # in the oracle's numbering
     ref = pr.vmult(s)[old_of_new]
     src = dev(s[old_of_new])
-    variants = [0, 10, 50] + ([3, 56, 59, 52] if p == 4 else [])
+    variants = [0, 10, 50] + ([3, 56, 49, 59, 52] if p == 4 else [])
     for v in variants:
         op.mf_data.set_apply_variant(v)
         op.mf_data.set_block_workgroups(8)
