@@ -190,7 +190,7 @@ def main():
             # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs) / average duration of the cell kernel
             # (HIP events on the solver's stream around that launch, inside the timed solve); `operator_ms` is the whole
             # application: zero-fill (atomic kernels) + cell kernel + combine pass (owner-scatter kernels); `traffic`: PMC bytes
-            "roofline": {"bound": "hbm", "kernel": tr["kernel"] if tr else {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: "apply_block_kernel<4,false,32,1,10240>"}.get(ev, f"apply variant {ev}"), "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": tr["kernel"] if tr else {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: "apply_block_kernel<4,false,32,1,288768>"}.get(ev, f"apply variant {ev}"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["traffic_bytes"] if tr else None, "algorithmic_bytes": B_op * n_dofs_local,
                          "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
