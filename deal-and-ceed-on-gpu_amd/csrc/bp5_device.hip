@@ -927,7 +927,7 @@ static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, 
       return fail(BP5_ERR_INVALID, "variant 57 needs the whole cell range");
     case 458: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 58 needs the whole cell range");
-    case 499: return launch_block_t<4, false, 32, 4096 + 2048 + 8192 + 16384>(mf, coef, src, dst, true);   // stamps, sequential tiles, 3 WG/CU, run write-out
+    case 499: return launch_block_t<4, false, 32, 4096 + 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, true);   // stamps of the default shape (sequential tiles, 3 WG/CU, run write-out, packed indices)
     case 452: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
     case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
