@@ -257,6 +257,18 @@ extern "C" int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups)
   mf->block_max_wg = max_workgroups;
   return BP5_OK;
 }
+static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block = 64);
+extern "C" int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, int *packed_indices)
+{
+  if (!mf || !n_blocks || !max_runs || !packed_indices) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan_raw(mf, -8, &dp, 64));
+  *n_blocks = dp->n_groups;
+  *max_runs = dp->max_runs;
+  *packed_indices = dp->packed != nullptr;
+  return BP5_OK;
+}
 extern "C" int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective)
 {
   if (!mf || !effective) return fail(BP5_ERR_INVALID, "null argument");
@@ -412,7 +424,7 @@ static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
 
 // key > 0: uniform teams of `key` cells (team kernel); key < 0: cell blocks walked in passes of
 // -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
-static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block = 64)
+static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
 {
   auto it = mf->plans.find(key);
   if (it == mf->plans.end()) {
@@ -427,13 +439,13 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     BP5_TRY(upload(&dp.dofs, h.dofs.data(), h.dofs.size()));
     std::vector<uint32_t> run_off, runs;
     if (key < 0) {
-      // run-length form of the sorted block lists: consecutive DoFs with equal ownership flag, cut at 2048 entries so
-      // that (run, offset) packs into 5 + 11 bits
+      // run-length form of the sorted block lists: consecutive DoFs with equal ownership flag, cut at 1024 entries so
+      // that (run, offset) packs into 6 + 10 bits
       run_off.assign(h.off.size(), 0);
       for (size_t g = 0; g + 1 < h.off.size(); ++g) {
         uint32_t start = h.off[g];
         for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i)
-          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1 || i - start == 2048) {
+          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1 || i - start == (1u << BLOCK_PACK_OFF_BITS)) {
             start = i;
             runs.push_back(i - h.off[g]);
             runs.push_back(h.dofs[i]);
@@ -444,7 +456,7 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
       // block kernel: per-cell index arrays in the pair layout of the z-pencils (two entries per load, see coef_off)
       const int n = mf->degree + 1, n2 = n * n;
       auto off = [&](int k, int ab) { return k < 2 * (n / 2) ? (k / 2) * (2 * n2) + 2 * ab + (k & 1) : (n / 2) * (2 * n2) + ab; };
-      std::vector<uint16_t> pos2(h.pos.size()), packed(dp.max_runs <= 32 ? h.pos.size() : 0);
+      std::vector<uint16_t> pos2(h.pos.size()), packed(dp.max_runs <= (uint32_t)BLOCK_PACK_MAX_RUNS ? h.pos.size() : 0);
       std::vector<uint32_t> gidx(h.pos.size());
 #pragma omp parallel
       {
@@ -467,7 +479,7 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
                 gidx[to] = mf->h_l2g[from];
                 if (!packed.empty()) {
                   const uint32_t sl = h.pos[from], r = run_of_slot[sl];
-                  packed[to] = (uint16_t)(r << 11 | (sl - runs[2 * (run_off[g] + r)]));
+                  packed[to] = (uint16_t)(r << BLOCK_PACK_OFF_BITS | (sl - runs[2 * (run_off[g] + r)]));
                 }
               }
         }
@@ -535,7 +547,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
   const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
-  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 32 runs per block: packed indices unavailable");
+  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 64 runs per block: packed indices unavailable");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
   BlockPlan bp{}; // value-initialised: a field this launcher forgets is null, not garbage
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;

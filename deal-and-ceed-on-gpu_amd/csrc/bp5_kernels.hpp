@@ -983,6 +983,8 @@ __device__ __forceinline__ void load_pencil_idx(const T *base, int ab, T (&v)[n]
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int BLOCK_MAX_RUNS = 128;
+constexpr int BLOCK_PACK_OFF_BITS = 10;                             // packed index = run << 10 | offset
+constexpr int BLOCK_PACK_MAX_RUNS = 1 << (16 - BLOCK_PACK_OFF_BITS); // 64
 struct BlockPlan {
   const uint32_t *pass_cell;  // [n_passes * CPT] cell id per slot; bit 31: idle slot (id still valid)
   const uint32_t *pass_off;   // [n_blocks+1] first pass of each block
@@ -990,8 +992,8 @@ struct BlockPlan {
   const uint32_t *dofs;       // sorted distinct DoFs per block; bit 31: touched by this block only
   const uint16_t *pos;        // [n_cells*n^3] position of each local DoF in its block's list, pair layout (coef_off(k, i + n j))
   const uint32_t *gidx;       // [n_cells*n^3] local_to_global in the same pair layout
-  // packed form (builds with ABL & 262144): ONE u16 per cell-local DoF = run << 11 | offset in the run (runs are cut at
-  // 2048 entries, at most 32 per block); list slot = run_slot[run] + offset, DoF = run_dof[run] + offset, both from the
+  // packed form (builds with ABL & 262144): ONE u16 per cell-local DoF = run << 10 | offset in the run (runs are cut at
+  // 1024 entries, at most 64 per block -- a boundary brick of a slab mesh with its ghost rows has 61); list slot = run_slot[run] + offset, DoF = run_dof[run] + offset, both from the
   // block's run table in LDS -- the local_to_global stream is not read at all
   const uint16_t *packed;     // [n_cells*n^3], pair layout
   const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
@@ -1099,7 +1101,7 @@ struct BlockPass {
   {
 #pragma unroll
     for (int k = 0; k < n; ++k) {
-      const uint32_t e = r.ps[k], run = e >> 11, off = e & 2047u;
+      const uint32_t e = r.ps[k], run = e >> BLOCK_PACK_OFF_BITS, off = e & ((1u << BLOCK_PACK_OFF_BITS) - 1u);
       const uint32_t dof = (rt[BLOCK_MAX_RUNS + run] & 0x7fffffffu) + off;
       r.ps[k] = (uint16_t)(rt[run] + off);
       r.u[k] = (ABL & 4) ? 1e-9 * dof : a.src[dof];

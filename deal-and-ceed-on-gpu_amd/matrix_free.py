@@ -138,6 +138,12 @@ class MatrixFree:
     def set_block_workgroups(self, n):
         _lib.check(_lib.lib().bp5_mf_set_block_workgroups(self.handle, int(n)))
 
+    def block_plan_info(self):
+        """(n_blocks, max_runs, packed_indices) of the block kernel's plan."""
+        nb, mr, pk = C.c_uint32(), C.c_uint32(), C.c_int()
+        _lib.check(_lib.lib().bp5_mf_block_plan_info(self.handle, C.byref(nb), C.byref(mr), C.byref(pk)))
+        return nb.value, mr.value, bool(pk.value)
+
     def get_apply_variant(self):
         """The kernel variant a whole-range application resolves to (what 0 = default means here)."""
         v = C.c_int()

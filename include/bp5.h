@@ -213,6 +213,10 @@ int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
 /* cap on the persistent grid of the block-assembled kernel (0 = sized from the CU count; tuning / tests: a small cap
  * makes every workgroup walk several blocks even on a small mesh) */
 int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups);
+/* facts about the block kernel's plan for this handle (builds it): number of cell blocks, longest run-length list of a
+ * block, and whether the packed one-u16-per-DoF index form is available (<= 64 runs per block; brick-major numbering
+ * gives 23-26, a slab's boundary bricks with their ghost rows 61) -- every rank of a multi-GPU run should report 1 */
+int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, int *packed_indices);
 /* the variant a whole-range application resolves to (what "0" means for this handle) */
 int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
 

@@ -131,6 +131,9 @@ def test_rank_local_kernels_with_ghosts(p, cells, n_ranks, kw, variant):
         op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
         op.mf_data.set_apply_variant(56 if kw.get("cell_block_order") == 1 else variant)   # (0 picks 56 only on large meshes)
         op.mf_data.set_block_workgroups(8)                # several bricks per persistent workgroup
+        if kw.get("cell_block_order") == 1:               # brick-major numbering: every rank gets the packed-index kernel,
+            nb, max_runs, packed = op.mf_data.block_plan_info()   # also the ranks whose boundary bricks carry ghost rows
+            assert packed and max_runs <= 64 and (max_runs > 32) == (r > 0)
         dst = op.initialize_dof_vector()
         assert dst.numel() == mesh.n_owned + mesh.n_ghost
         op.mf_data.cell_loop(op.coef, dev(s[g]), dst)
