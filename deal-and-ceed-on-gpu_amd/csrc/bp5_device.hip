@@ -533,8 +533,6 @@ static int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set
   return BP5_OK;
 }
 
-constexpr size_t BLOCK_LDS_BUDGET = 80 * 1024; // two workgroups per CU (160 KiB LDS)
-
 // block-assembled kernel; falls back to the team kernel path when the range is partial
 template <int P, bool COLL, int LPC, int ABL = 0>
 static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, double *dst, bool overwrite)

@@ -1500,7 +1500,6 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   constexpr int TEAM = 256;
   constexpr int CPT = TEAM / LPC;
   static_assert(LPC >= n2 && CPT >= 1, "lanes per cell");
-  using L = LdsLayout<n, LPC>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *acc = lds + CPT * BP::TILE_CS; // accumulator behind the transpose tiles
 
