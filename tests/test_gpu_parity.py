@@ -286,6 +286,38 @@ def test_block_kernel_persistent_loop_over_unequal_blocks(variant, cells):
         assert rel(c.cpu().numpy(), refc) < TOL_OP
 
 
+@pytest.mark.parametrize("block,cells,numbering,order", [((4, 4, 2), (9, 6, 5), 1, 1), ((2, 2, 2), (5, 4, 3), 1, 0), ((5, 3, 4), (11, 7, 9), 1, 1),
+                                                         ((3, 3, 3), (7, 7, 4), 1, 1), ((4, 4, 4), (9, 5, 6), 0, 1), ((8, 2, 2), (17, 5, 3), 1, 0)])
+def test_default_block_kernel_on_other_brick_shapes(block, cells, numbering, order):
+    """The p = 4 default shape (packed indices when the lists have <= 64 runs, else run-length or list write-out) on
+    bricks that are not 4x4x4: odd edge lengths (uneven parity classes -> under-full and multi-round passes), flat and
+    long bricks, lexicographic numbering (hundreds of short runs -> unpacked fallback); several bricks per workgroup."""
+    torch = _t()
+    p = 4
+    pr = O.Problem(p, cells, 0, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, deform_amp=0.03, cell_block=block, dof_numbering=numbering, cell_block_order=order)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    nb, max_runs, packed = op.mf_data.block_plan_info()
+    assert packed == (max_runs <= 64) and (numbering == 1 or not packed)
+    s = O.deterministic_src(mesh.n_owned, seed=53)
+    ref = pr.vmult(s)[perm]
+    refc = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]
+    for v in (56, 49):
+        op.mf_data.set_apply_variant(v)
+        op.mf_data.set_block_workgroups(8)
+        d1 = op.initialize_dof_vector()
+        d1.fill_(float("nan"))
+        op.vmult(d1, dev(s[perm]))
+        assert rel(d1.cpu().numpy(), ref) < TOL_OP
+        d2 = op.initialize_dof_vector()
+        op.vmult(d2, dev(s[perm]))
+        assert torch.equal(d1, d2)
+        c = op.initialize_dof_vector()
+        op.mf_data.cell_loop(op.coef, dev(s[perm]), c)
+        assert rel(c.cpu().numpy(), refc) < TOL_OP
+
+
 @pytest.mark.parametrize("quad", [0, 1])
 def test_block_kernel_on_block_aligned_cell_ranges(quad):
     """bp5_apply_cells with the block kernel on cell ranges that are unions of whole bricks (what a host that
