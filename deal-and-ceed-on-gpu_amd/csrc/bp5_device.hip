@@ -48,6 +48,7 @@ struct bp5_mf {
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
   uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
+  bool combine_csr = false; // A/B: per-DoF CSR combine kernel instead of the run-length one
   int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
   int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
@@ -86,6 +87,7 @@ struct bp5_mf {
     double *partial = nullptr;
     uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
     uint16_t *packed = nullptr;
+    uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
   };
@@ -217,7 +219,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile};
     for (void *x : pp) if (x) hipFree(x);
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
@@ -505,6 +507,38 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
       BP5_TRY(upload(&dp.runs, runs.data(), runs.size()));
     }
     dp.n_shared = (uint32_t)h.sh_dof.size();
+    if (dp.n_shared) { // run-length form of the shared-DoF CSR for combine_runs_kernel
+      std::vector<uint32_t> start, dof0, soff, slots, tile;
+      const size_t ns = h.sh_dof.size();
+      for (size_t i = 0; i < ns; ++i) {
+        const uint32_t b = h.sh_off[i], e = h.sh_off[i + 1];
+        bool cont = i > 0 && h.sh_dof[i] == h.sh_dof[i - 1] + 1 && (e - b) == (h.sh_off[i] - h.sh_off[i - 1]);
+        for (uint32_t q = 0; cont && q < e - b; ++q) cont = h.sh_slot[b + q] == h.sh_slot[h.sh_off[i - 1] + q] + 1;
+        if (!cont) {
+          start.push_back((uint32_t)i);
+          dof0.push_back(h.sh_dof[i]);
+          soff.push_back((uint32_t)slots.size());
+          slots.insert(slots.end(), h.sh_slot.begin() + b, h.sh_slot.begin() + e);
+        }
+      }
+      start.push_back((uint32_t)ns);
+      soff.push_back((uint32_t)slots.size());
+      const size_t n_tiles = (ns + 255) / 256;
+      tile.resize(n_tiles + 1);
+      size_t r = 0;
+      for (size_t t = 0; t <= n_tiles; ++t) { // run containing ordinal min(256 t, ns - 1)
+        const size_t i = std::min(t * 256, ns - 1);
+        while (start[r + 1] <= i) ++r;
+        tile[t] = (uint32_t)r;
+      }
+      start.push_back((uint32_t)ns); // one entry of slack for the staging loop (reads r_hi + 1)
+      soff.push_back((uint32_t)slots.size());
+      BP5_TRY(upload(&dp.cr_start, start.data(), start.size()));
+      BP5_TRY(upload(&dp.cr_dof0, dof0.data(), dof0.size()));
+      BP5_TRY(upload(&dp.cr_soff, soff.data(), soff.size()));
+      BP5_TRY(upload(&dp.cr_slots, slots.data(), slots.size()));
+      BP5_TRY(upload(&dp.cr_tile, tile.data(), tile.size()));
+    }
     dp.covers_all = h.covers_all;
     dp.n_groups = (uint32_t)h.group_cell_off.size() - 1;
     for (uint32_t g = 0; g < dp.n_groups; ++g) dp.max_list = std::max(dp.max_list, h.off[g + 1] - h.off[g]);
@@ -527,6 +561,13 @@ static int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set
   if (!dp->n_shared) return BP5_OK;
   if (mf->prof_mark) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
   const dim3 cg((dp->n_shared + 255) / 256);
+  if (dp->cr_tile && !mf->combine_csr) {
+    const CombineRuns cr{dp->cr_start, dp->cr_dof0, dp->cr_soff, dp->cr_slots, dp->cr_tile, dp->n_shared};
+    if (set) hipLaunchKernelGGL(combine_runs_kernel<false>, cg, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    else hipLaunchKernelGGL(combine_runs_kernel<true>, cg, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    KERNEL_CHECK();
+    return BP5_OK;
+  }
   if (set) hipLaunchKernelGGL(combine_kernel<false>, cg, dim3(256), 0, mf->stream, dp->sh_dof, dp->sh_off, dp->sh_slot, dp->partial, dst, dp->n_shared);
   else hipLaunchKernelGGL(combine_kernel<true>, cg, dim3(256), 0, mf->stream, dp->sh_dof, dp->sh_off, dp->sh_slot, dp->partial, dst, dp->n_shared);
   KERNEL_CHECK();
@@ -769,7 +810,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 static bool variant_overwrites(const bp5_mf *mf, int ev)
 {
   const int v = ev % 100;
-  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 49 && v <= 59)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 59)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
 }
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
@@ -918,9 +959,11 @@ static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, 
         return st_;
       }
       return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
+    case 448: // = 56 with the per-DoF CSR combine kernel instead of the run-length one (A/B)
     case 449: // = 56 with run-length write-out but without packed indices (A/B)
     case 456: if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
-        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
+        mf->combine_csr = variant == 48;
         bp5_mf::DevPlan *dp_ = nullptr;
         BP5_TRY(get_plan_raw(mf, -8, &dp_));
         if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream

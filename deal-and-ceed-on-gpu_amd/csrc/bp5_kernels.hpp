@@ -1978,6 +1978,42 @@ __global__ void __launch_bounds__(256) combine_kernel(const uint32_t *sh_dof, co
   if (ADD) dst[g] += s; else dst[g] = s;
 }
 
+// The same sums from a run-length form of the CSR: consecutive shared DoFs whose partial slots are consecutive in every
+// contributing group (a brick face is one run of 225 DoFs in both bricks' lists) share one record
+//   run r: shared-DoF ordinals [start[r], start[r+1]), first DoF dof0[r], first slot per contributing group slots[soff[r] + q]
+// Tile T (256 ordinals) touches the runs tile_run[T] .. tile_run[T+1]; their records are staged in LDS and every thread
+// finds its run there.  Same summation order as combine_kernel (groups in ascending order): bitwise identical results,
+// about half the bytes (no per-DoF index arrays).
+struct CombineRuns {
+  const uint32_t *start, *dof0, *soff, *slots, *tile_run;
+  uint32_t n_shared;
+};
+template <bool ADD>
+__global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const double *partial, double *dst)
+{
+  __shared__ uint32_t s_start[258], s_dof0[257], s_soff[258];
+  const uint32_t r_lo = cr.tile_run[blockIdx.x], r_hi = cr.tile_run[blockIdx.x + 1]; // inclusive range, r_hi - r_lo <= 256
+  const uint32_t cnt = r_hi - r_lo + 1;
+  for (uint32_t j = threadIdx.x; j <= cnt; j += 256) {
+    s_start[j] = cr.start[r_lo + j];
+    s_soff[j] = cr.soff[r_lo + j];
+    if (j < cnt) s_dof0[j] = cr.dof0[r_lo + j];
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= cr.n_shared) return;
+  uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (s_start[mid] <= i) lo = mid; else hi = mid;
+  }
+  const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
+  double s = partial[cr.slots[b] + j];
+  for (uint32_t q = b + 1; q < e; ++q) s += partial[cr.slots[q] + j];
+  const uint32_t g = s_dof0[lo] + j;
+  if (ADD) dst[g] += s; else dst[g] = s;
+}
+
 __global__ void __launch_bounds__(256) zero_indexed_kernel(const uint32_t *idx, uint32_t n, double *dst)
 {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
