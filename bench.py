@@ -196,7 +196,7 @@ def main():
                          "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
                          "operator_ms": ctl.operator_ms_avg},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             # bounded sample of the same workload family: ~10 s of host CPU work
             out["cpu_baseline"] = cpu_baseline(p, quad, (48, 48, 48) if p <= 4 else (24, 24, 24), 120, args.deform, km)
         print(json.dumps(out), flush=True)
