@@ -957,10 +957,17 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 // DoFs; after the last pass DoFs touched by this brick only are stored with plain stores and
 // the brick-surface DoFs go to a per-brick partial slab that combine_kernel sums in a fixed
 // order: no global atomics, no zero-fill of dst, bitwise reproducible.
-// The accumulator limits residency to two workgroups per CU, so memory latency is hidden by
-// software pipelining instead of occupancy: while pass q computes, the indices, the gathered src
-// values and all six metric planes of pass q+1 are already in flight into a second register set
-// (the kernel may use the full 256 VGPRs at 2 waves per SIMD).
+// Build flags (ABL) select the shape.  First version: three transpose tiles per cell and a second register set
+// (double-buffered prefetch of the next pass: indices, gathered src values, all six metric planes), two workgroups per
+// CU.  Default at p = 4 (variant 56 = 2048 | 8192 | 16384 | 262144), all measured steps in profiles/r1/README.md:
+//   2048    single register set: 151-167 VGPRs -> three waves per SIMD
+//   8192    ONE transpose tile per cell, used field after field (32 lanes per cell: tile syncs are wave-local and
+//           free) -> tiles + 17^3 accumulator + run tables = 49.5 KB -> three workgroups per CU
+//   16384   run-length write-out: the brick's sorted DoF list as <= 64 runs in LDS, 16-byte stores, no list loads
+//   262144  packed indices: one u16 (run << 10 | offset) per cell-local DoF gives both the accumulator slot and the
+//           DoF to gather through that run table; local_to_global is not read
+// With the metric in the pair layout (coef_off) a lane issues 18 + 3 + 5 + 1 load instructions per cell.
+
 // the same pair layout for the block plan's per-cell index arrays (z-pencil of lane ab = i + n j, entries k = 0..n-1)
 template <int n, typename T>
 __device__ __forceinline__ void load_pencil_idx(const T *base, int ab, T (&v)[n])
