@@ -666,7 +666,7 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     fprintf(stderr, "[bp5 stamps] passes/wg %.1f, cycles/pass %.0f\n", tot[8] / n_wg, all / tot[8]);
     for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
   }
-  if (ABL & 1023) return BP5_OK; // (65536 is a real mode too) timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
+  if (ABL & 1023) return BP5_OK; // (1024 and above are real modes) timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
   return launch_combine(mf, dp, dst, set);
 }
 
@@ -784,9 +784,9 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
   if (v != 0) return v;
   if (mf->degree == 1 || mf->degree == 3) return mf->geometry_mode == BP5_GEOM_AFFINE ? 0 : 10;
   if (mf->degree != 4) return 0;
-  if (mf->geometry_mode == BP5_GEOM_AFFINE) return 10;
+  const int fallback = mf->geometry_mode == BP5_GEOM_AFFINE ? 10 : 0; // affine: team kernel, else pencil kernel
   uint32_t b0_, b1_;
-  if (mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &b0_, &b1_)) return 0;
+  if (mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &b0_, &b1_)) return fallback;
   if (mf->auto_block < 0) {
     bp5_mf::DevPlan *dp = nullptr;
     mf->auto_block = 0;
@@ -803,8 +803,12 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     }
   }
   // sub-ranges: worth it only while the range still feeds the persistent grid (else the pencil kernel)
-  if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (b1_ - b0_) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return 0;
-  return mf->auto_block ? 56 : 0;
+  if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (b1_ - b0_) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return fallback;
+  if (mf->auto_block && mf->geometry_mode == BP5_GEOM_AFFINE) { // the affine build needs the packed indices
+    bp5_mf::DevPlan *dp = nullptr;
+    if (get_plan_raw(mf, -8, &dp, 64) != BP5_OK || !dp->packed) return fallback;
+  }
+  return mf->auto_block ? 56 : fallback;
 }
 // kernels that define every entry of dst themselves (owner stores + combine pass) need no zero-fill
 static bool variant_overwrites(const bp5_mf *mf, int ev)
@@ -822,6 +826,12 @@ static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, 
       mf->force_atomic_scatter = mf->apply_variant >= 100;
       return coll_ ? launch_team_t<4, true, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite)
                    : launch_team_t<4, false, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite);
+    }
+    if (mf->degree == 4 && mf->apply_variant == 56) { // the default block-kernel shape on the scalar plane + per-cell K K^T
+      if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
+      struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+      return coll_ ? launch_block_t<4, true, 32, 1024 + 2048 + 8192 + 16384 + 262144>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                   : launch_block_t<4, false, 32, 1024 + 2048 + 8192 + 16384 + 262144>(mf, mf->d_scalar_plane, src, dst, overwrite);
     }
     if (mf->degree == 4 && whole && (mf->apply_variant == 54 || mf->apply_variant == 55)) {
       mf->block_shared_atomic = true;

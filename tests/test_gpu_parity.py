@@ -714,7 +714,8 @@ def test_medium_size_against_c_oracle():
     (1, (150, 140, 130), 0, 0.03, 1, {}, 10), (3, (61, 60, 59), 1, 0.03, 1, {}, 10),                  # team-kernel defaults at scale
     (2, (81, 80, 79), 0, 0.03, 0, {}, 0), (5, (33, 32, 31), 1, 0.03, 1, {}, 0), (7, (23, 22, 21), 0, 0.03, 1, {}, 0),
     (8, (20, 19, 18), 1, 0.03, 1, {}, 0),
-    (4, (60, 59, 58), 0, 0.0, 1, dict(geometry="affine"), 10), (6, (30, 29, 28), 0, 0.0, 1, dict(geometry="affine"), 0)])
+    (4, (60, 59, 58), 0, 0.0, 1, dict(geometry="affine"), 10), (6, (30, 29, 28), 0, 0.0, 1, dict(geometry="affine"), 0),
+    (4, (86, 84, 82), 1, 0.0, 1, dict(geometry="affine", cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56)])
 def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     """Size-independent properties at BASELINE scale: constants in the null space of the cell
     loop, symmetry, linearity; CG residual consistency.  The third case is the bench's mesh ordering
