@@ -1098,7 +1098,7 @@ extern "C" int bp5_assemble_rhs(bp5_mf *mf, double *b)
   HIP_TRY(hipSetDevice(mf->device));
   HIP_TRY(hipMemsetAsync(b, 0, mf->n_local() * sizeof(double), mf->stream));
   BP5_TRY(rhs_dispatch(mf, b));
-  if (mf->comm && mf->comm->n_ranks > 1) BP5_TRY(bp5_halo_scatter_add(mf, b));
+  if (mf->comm && !mf->neighbors.empty()) BP5_TRY(bp5_halo_scatter_add(mf, b));
   return bp5_set_constrained(mf, 0.0, b);
 }
 template <int n>
@@ -1118,7 +1118,7 @@ extern "C" int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag
   HIP_TRY(hipSetDevice(mf->device));
   HIP_TRY(hipMemsetAsync(diag, 0, mf->n_local() * sizeof(double), mf->stream));
   if (mf->n_cells) BP5_TRY(diagonal_dispatch(mf, coef, diag));
-  if (mf->comm && mf->comm->n_ranks > 1) { // ghost contributions to their owners
+  if (mf->comm && !mf->neighbors.empty()) { // ghost contributions to their owners
     BP5_TRY(bp5_halo_scatter_add(mf, diag));
     BP5_TRY(bp5_halo_zero_ghosts(mf, diag));
   }
@@ -1416,7 +1416,7 @@ struct ApplyProfile {
 // A.vmult(h, d) inside the solvers: dst already zero on entry when zeroed == true
 static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof)
 {
-  const bool dist = mf->comm && mf->comm->n_ranks > 1;
+  const bool dist = mf->comm && !mf->neighbors.empty(); // halo exchange: whenever there are neighbours (tests: a self neighbour)
   if (dist) BP5_TRY(bp5_halo_gather(mf, src));
   // kernels that accumulate with atomics need a zeroed target (owner-scatter kernels define every entry themselves)
   const bool owner_scatter = variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells));

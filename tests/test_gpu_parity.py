@@ -856,6 +856,121 @@ def test_externally_numbered_mesh(p, cells, seed):
         assert rel(x.cpu().numpy(), xr[old_of_new]) < TOL_CG, v
 
 
+def test_halo_exchange_through_rccl_with_a_self_neighbour():
+    """The halo path with REAL RCCL traffic on one GPU: a one-rank communicator whose only neighbour is the rank
+    itself (RCCL supports send/recv to self inside a group).  The slab mesh of rank 1 of 2 supplies cells that read
+    ghost DoFs; the 'owner' of the ghost plane is faked to be this rank's own top DoF plane.  Checked against the
+    same steps done with torch indexing: gather (pack kernel, ncclSend/ncclRecv into the ghost range), all cells,
+    scatter-add (ncclSend/ncclRecv, unpack-add kernel in a fixed order), ghost zeroing, Dirichlet copy."""
+    from types import SimpleNamespace
+    torch = _t()
+    import ctypes as C
+    p, cells = 3, (4, 3, 5)
+    m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=2)
+    ng, no = m1.n_ghost, m1.n_owned
+    assert ng > 0
+    send_idx = np.arange(no - ng, no, dtype=np.uint32)          # this rank's last owned DoFs play the neighbour's plane
+    mesh = SimpleNamespace(degree=p, n=p + 1, cells=cells, n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
+                           n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
+                           n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32), send_indices=send_idx,
+                           recv_offsets=np.asarray([0, ng], np.uint32), cell_block_offsets=None, rank=0, n_ranks=1, h=1.0, deform_amp=0.03)
+    comm = pkg.Communicator(0, 1)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64, comm=comm)
+    L, h = pkg.lib(), op.mf_data.handle
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    v = torch.rand(no + ng, dtype=torch.float64, device="cuda:0", generator=g)
+    ref = v.clone()
+    ref[no:] = ref[torch.from_numpy(send_idx.astype(np.int64)).cuda()]
+    assert L.bp5_halo_gather(h, ptr(v)) == 0
+    assert torch.equal(v, ref)
+    w = torch.rand(no + ng, dtype=torch.float64, device="cuda:0", generator=g)
+    refw = w.clone()
+    refw[torch.from_numpy(send_idx.astype(np.int64)).cuda()] += refw[no:]
+    refw[no:] = 0.0
+    assert L.bp5_halo_scatter_add(h, ptr(w)) == 0
+    assert torch.equal(w, refw)
+    # the whole distributed application against the same steps by hand
+    src = torch.rand(no + ng, dtype=torch.float64, device="cuda:0", generator=g)
+    src[no:] = 0.0
+    s2 = src.clone()
+    s2[no:] = s2[torch.from_numpy(send_idx.astype(np.int64)).cuda()]
+    want = op.initialize_dof_vector()
+    op.mf_data.cell_loop(op.coef, s2, want)
+    want[torch.from_numpy(send_idx.astype(np.int64)).cuda()] += want[no:]
+    want[no:] = 0.0
+    c = torch.from_numpy(m1.constrained.astype(np.int64)).cuda()
+    want[c] = src[c]
+    got = op.initialize_dof_vector()
+    got.fill_(float("nan"))
+    src_in = src.clone()
+    assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(src_in), ptr(got), 1) == 0
+    assert float((got - want).abs().max()) < 1e-12 * float(want.abs().max())
+    assert float(src_in[no:].abs().max()) == 0.0        # ghosts of src zeroed again
+    # CG with the exchange inside every operator application (solver path of an N > 1 run): the glued mesh is still
+    # SPD on the free DoFs, so the recurrence residual must equal the true residual computed through the same operator
+    b = op.assemble_rhs()                                # ghost contributions travel to their (faked) owners
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(12, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        Ax = op.initialize_dof_vector()
+        xin = x.clone()
+        assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(xin), ptr(Ax), 1) == 0
+        true_res = float(torch.linalg.norm((Ax - b)[:no]))
+        assert ctl.last_step() == 12 and abs(true_res - ctl.last_value()) < 1e-9 * ctl.initial_value()
+        assert ctl.last_value() < 0.5 * ctl.initial_value()
+    op.mf_data.synchronize()
+    op.mf_data.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("variant", [56, 3])
+def test_block_kernel_behind_the_halo_exchange(variant):
+    """The bench's rank-local configuration for ranks > 0 (brick-ordered slab mesh with a ghost plane, block kernel with
+    packed indices, overwrite mode) inside bp5_apply_distributed with real RCCL traffic (self neighbour): equals the
+    atomic pencil kernel through the same exchange."""
+    from types import SimpleNamespace
+    torch = _t()
+    import ctypes as C
+    p, cells = 4, (9, 8, 10)
+    m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=2, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+    ng, no = m1.n_ghost, m1.n_owned
+    send_idx = np.arange(no - ng, no, dtype=np.uint32)
+    mesh = SimpleNamespace(degree=p, n=p + 1, cells=cells, n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
+                           n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
+                           n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32), send_indices=send_idx,
+                           recv_offsets=np.asarray([0, ng], np.uint32), cell_block_offsets=m1.cell_block_offsets, rank=0, n_ranks=1, h=1.0,
+                           deform_amp=0.03)
+    comm = pkg.Communicator(0, 1)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64, comm=comm)
+    L, h = pkg.lib(), op.mf_data.handle
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.Generator(device="cuda:0").manual_seed(6)
+    src = torch.rand(no + ng, dtype=torch.float64, device="cuda:0", generator=g)
+    src[no:] = 0.0
+    outs = []
+    for v in (3, variant):
+        op.mf_data.set_apply_variant(v)
+        op.mf_data.set_block_workgroups(8)
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        s_in = src.clone()
+        assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(s_in), ptr(d), 1) == 0
+        outs.append(d)
+    assert float((outs[1] - outs[0]).abs().max()) < 1e-12 * float(outs[0].abs().max())
+    b = op.assemble_rhs()
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(10, 0.0)
+    pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+    Ax, xin = op.initialize_dof_vector(), x.clone()
+    assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(xin), ptr(Ax), 1) == 0
+    assert abs(float(torch.linalg.norm((Ax - b)[:no])) - ctl.last_value()) < 1e-9 * ctl.initial_value()
+    op.mf_data.synchronize()
+    op.mf_data.close()
+    comm.close()
+
+
 # ------------------------------------------------------------------ edge cases
 def test_single_cell_and_tiny_meshes():
     """one cell (every DoF on the Dirichlet boundary except the interior ones), p = 1 and p = 8"""
