@@ -1145,7 +1145,7 @@ extern "C" int bp5_l2_norm_solution(bp5_mf *mf, const double *u, double *result)
   HIP_TRY(hipSetDevice(mf->device));
   HIP_TRY(hipMemsetAsync(mf->d_scalar, 0, sizeof(double), mf->stream));
   BP5_TRY(l2_dispatch(mf, u, mf->d_scalar));
-  if (mf->comm && mf->comm->n_ranks > 1) BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_scalar, 1));
+  if (mf->comm) BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_scalar, 1));
   double s = 0.0;
   HIP_TRY(hipMemcpyAsync(&s, mf->d_scalar, sizeof(double), hipMemcpyDeviceToHost, mf->stream));
   HIP_TRY(hipStreamSynchronize(mf->stream));
@@ -1212,7 +1212,7 @@ static int reduce_to_host(bp5_mf *mf, int grid, double *result)
 {
   hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, mf->stream, mf->d_partials, grid, mf->d_scalar, (const int *)nullptr);
   KERNEL_CHECK();
-  if (mf->comm && mf->comm->n_ranks > 1) NCCL_TRY(ncclAllReduce(mf->d_scalar, mf->d_scalar, 1, ncclDouble, ncclSum, mf->comm->comm, mf->stream));
+  if (mf->comm) NCCL_TRY(ncclAllReduce(mf->d_scalar, mf->d_scalar, 1, ncclDouble, ncclSum, mf->comm->comm, mf->stream));
   HIP_TRY(hipMemcpyAsync(result, mf->d_scalar, sizeof(double), hipMemcpyDeviceToHost, mf->stream));
   HIP_TRY(hipStreamSynchronize(mf->stream));
   return BP5_OK;
@@ -1280,7 +1280,7 @@ extern "C" int bp5_mf_set_comm(bp5_mf *mf, bp5_comm *comm)
 extern "C" int bp5_comm_allreduce_sum(bp5_mf *mf, double *buf, size_t n)
 {
   if (!mf || !buf) return fail(BP5_ERR_INVALID, "null argument");
-  if (!mf->comm || mf->comm->n_ranks == 1) return BP5_OK;
+  if (!mf->comm) return BP5_OK; // (a one-rank communicator still goes through RCCL: the single-GPU tests exercise the call)
   NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, mf->comm->comm, mf->stream));
   return BP5_OK;
 }
