@@ -87,6 +87,9 @@ struct bp5_mf {
     double *partial = nullptr;
     uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
     uint16_t *packed = nullptr;
+    std::vector<double> h_cost;                       // [n_groups+1] prefix sum of the estimated cost of the blocks (pass units)
+    uint32_t *wg_block = nullptr;                     // cached ranges for (wg_n, wg_b0, wg_b1)
+    uint32_t wg_n = 0, wg_b0 = 0, wg_b1 = 0;
     uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
@@ -219,7 +222,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile, q.wg_block};
     for (void *x : pp) if (x) hipFree(x);
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
@@ -502,6 +505,14 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     if (key < 0) {
       BP5_TRY(upload(&dp.pass_cell, h.pass_cell.data(), h.pass_cell.size()));
       BP5_TRY(upload(&dp.pass_off, h.pass_off.data(), h.pass_off.size()));
+      // cost model of a block in units of one pass, calibrated on the slab mesh of a rank > 0 (profiles/r1 k_*: thin
+      // boundary bricks next to full ones): every accumulation round after the first +0.18, the write-out 1.5 per 4913
+      // list slots, ONE pass-equivalent fixed per block (barrier, block switch, table hand-over)
+      dp.h_cost.assign(h.pass_off.size(), 0.0);
+      for (size_t g = 0; g + 1 < h.pass_off.size(); ++g) {
+        const double passes = h.pass_off[g + 1] - h.pass_off[g], rounds = h.team_rounds[g], m = h.off[g + 1] - h.off[g];
+        dp.h_cost[g + 1] = dp.h_cost[g] + passes * (1.0 + 0.18 * (rounds - 1.0)) + 1.5 * m / 4913.0 + 1.0;
+      }
       runs.push_back(0); runs.push_back(0);
       BP5_TRY(upload(&dp.run_off, run_off.data(), run_off.size()));
       BP5_TRY(upload(&dp.runs, runs.data(), runs.size()));
@@ -610,6 +621,22 @@ static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
   bp.n_wg = n_wg;
+  { // block ranges of the persistent workgroups: equal shares of the estimated COST (thin or partial bricks are cheaper per
+    // block but dearer per cell than full ones), cached
+    const uint32_t B0 = bp.blk_begin, B1 = bp.blk_begin + bp.n_blocks;
+    if (!dp->wg_block || dp->wg_n != n_wg || dp->wg_b0 != B0 || dp->wg_b1 != B1) {
+      std::vector<uint32_t> wb(n_wg + 1);
+      const std::vector<double> &pc = dp->h_cost;
+      const double c0 = pc[B0], total = pc[B1] - c0;
+      for (uint32_t w = 0; w <= n_wg; ++w)
+        wb[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + B1 + 1, c0 + total * w / n_wg - 1e-9) - pc.begin());
+      wb[0] = B0; wb[n_wg] = B1;
+      if (dp->wg_block) { HIP_TRY(hipStreamSynchronize(mf->stream)); HIP_TRY(hipFree(dp->wg_block)); dp->wg_block = nullptr; }
+      BP5_TRY(upload(&dp->wg_block, wb.data(), wb.size()));
+      dp->wg_n = n_wg; dp->wg_b0 = B0; dp->wg_b1 = B1;
+    }
+    bp.wg_block = dp->wg_block;
+  }
   bp.stamps = nullptr;
   if (ABL & 4096) {
     if (!mf->d_stamps) HIP_TRY(hipMalloc((void **)&mf->d_stamps, 4096 * 16 * sizeof(unsigned long long)));

@@ -1008,6 +1008,7 @@ struct BlockPlan {
   double *partial;            // [off[n_blocks]]
   uint32_t n_blocks, n_wg;    // blocks of this launch; persistent workgroups, n_wg a multiple of 8
   uint32_t blk_begin;         // first block of this launch (block-aligned cell ranges; 0 for the whole mesh)
+  const uint32_t *wg_block;   // [n_wg+1] first block of every persistent workgroup: ranges balanced by PASSES, not blocks
   // run-length form of dofs (builds with ABL & 16384): run r of block b covers the list slots [runs[2r], runs[2r+2]) and
   // the consecutive DoFs starting at runs[2r+1] (bit 31 as in dofs); at most BLOCK_MAX_RUNS runs per block
   const uint32_t *run_off;    // [n_blocks+1]
@@ -1515,8 +1516,8 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   // persistent workgroup w owns the contiguous block range [b0,b1); workgroups that share an XCD
   // (blockIdx % 8, speed only) own neighbouring ranges
   const uint32_t w = (blockIdx.x & 7u) * (bp.n_wg >> 3) + (blockIdx.x >> 3);
-  uint32_t b = bp.blk_begin + (uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg);
-  const uint32_t b1 = bp.blk_begin + (uint32_t)((uint64_t)(w + 1) * bp.n_blocks / bp.n_wg);
+  uint32_t b = bp.wg_block[w];
+  const uint32_t b1 = bp.wg_block[w + 1];
   if (b >= b1) return;
   uint32_t gp = bp.pass_off[b];
   const uint32_t gp_end = bp.pass_off[b1];
@@ -1570,15 +1571,28 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   // not wait on dependent loads; entries beyond MAXW per thread (very large blocks) take the slow path.
   constexpr int MAXW = (ABL & 2048) ? 1 : 6; // registers are scarce (the single-buffered build is capped at 168)
   uint32_t gl[MAXW];
+  // bookkeeping scalars of the NEXT block, fetched at the top of this block's last pass so that the block switch
+  // does not wait for them
+  uint32_t nx_boundary = 0, nx_o0 = 0, nx_o1 = 0, nx_r0 = 0, nx_r1 = 0;
+  int nx_rounds = 1;
   auto prefetch_list = [&]() {
+    if (gp + 1 == boundary && b + 1 < b1) {
+      nx_boundary = bp.pass_off[b + 2];
+      nx_o0 = bp.off[b + 1];
+      nx_o1 = bp.off[b + 2];
+      nx_rounds = bp.blk_rounds[b + 1];
+      if constexpr (RUNS) {
+        nx_r0 = bp.run_off[b + 1];
+        nx_r1 = bp.run_off[b + 2];
+      }
+    }
     if (gp + 1 == boundary) {
       if constexpr (BP::PACK) {
         // table of the NEXT block (this block's own table has been in LDS since the end of the previous block)
         if (b + 1 < b1) {
-          const uint32_t rn = bp.run_off[b + 1];
-          if (t < (int)(bp.run_off[b + 2] - rn)) {
-            run_slot = bp.runs[2 * (rn + t)];
-            run_dof = bp.runs[2 * (rn + t) + 1];
+          if (t < (int)(nx_r1 - nx_r0)) {
+            run_slot = bp.runs[2 * (nx_r0 + t)];
+            run_dof = bp.runs[2 * (nx_r0 + t) + 1];
           }
         }
       } else if constexpr (RUNS) {
@@ -1639,7 +1653,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
         // block's first accumulation barrier
         if (b + 1 < b1) {
           uint32_t *const rn = run_tab + ((b + 1) & 1u) * (2 * BLOCK_MAX_RUNS);
-          if (t < (int)(bp.run_off[b + 2] - bp.run_off[b + 1])) {
+          if (t < (int)(nx_r1 - nx_r0)) {
             rn[t] = run_slot;
             rn[BLOCK_MAX_RUNS + t] = run_dof;
           }
@@ -1682,13 +1696,13 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       }
       ++b;
       if (b < b1) {
-        boundary = bp.pass_off[b + 1];
-        o0 = bp.off[b];
-        m = (int)(bp.off[b + 1] - o0);
-        n_rounds = bp.blk_rounds[b];
+        boundary = nx_boundary;
+        o0 = nx_o0;
+        m = (int)(nx_o1 - nx_o0);
+        n_rounds = nx_rounds;
         if constexpr (RUNS) {
-          r0 = bp.run_off[b];
-          n_runs = (int)(bp.run_off[b + 1] - r0);
+          r0 = nx_r0;
+          n_runs = (int)(nx_r1 - nx_r0);
         }
       }
       // no barrier here: the next pass starts with tile work and reaches the accumulation barrier before it
@@ -1720,7 +1734,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     if (t == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) bp.stamps[(uint64_t)w * 16 + k] = ph[k];
-      bp.stamps[(uint64_t)w * 16 + 8] = gp_end - bp.pass_off[bp.blk_begin + (uint32_t)((uint64_t)w * bp.n_blocks / bp.n_wg)];
+      bp.stamps[(uint64_t)w * 16 + 8] = gp_end - bp.pass_off[bp.wg_block[w]];
     }
   }
 }
