@@ -194,7 +194,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["traffic_bytes"] if tr else None, "algorithmic_bytes": B_op * n_dofs_local,
                          "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
-                         "operator_ms": ctl.operator_ms_avg},
+                         "operator_ms": ctl.operator_ms_avg,
+                         "algorithmic_formula": f"16 + I*4r + G*8r B/DoF with I=1, G={G} (SURVEY 8d)"
+                                                + ("; the block kernel's own index stream is 2r B/DoF (packed run/offset), local_to_global is not read" if ev == 56 else "")},
         }
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             # bounded sample of the same workload family: ~10 s of host CPU work
