@@ -2,17 +2,22 @@
 """BP5 benchmark: DoFs/s per CG iteration on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
 
-A "step" is one CG iteration (operator apply + vector updates + dot products) of the fused
-solver on the p=4, ~1e8-DoF synthetic hex mesh; W warm-up iterations, then a solve of exactly K
-iterations is timed between barrier + synchronize pairs, max over ranks (the reference's protocol
-times the whole cg.solve too: bp5/step-64.cu:442-463).  N > 1 is weak scaling: every rank owns a
-z-slab of the same size as the N = 1 problem.  Prints ONE JSON line on rank 0.
+A "step" is one CG iteration (operator apply + vector updates + dot products) of the fused solver on the
+p=4, 116^3-cell, 100 544 625-DoF synthetic hex mesh (BASELINE config 3; at N = 1 the whole problem sits on one
+GPU).  W warm-up iterations, then a solve of exactly K iterations is timed between barrier + synchronize pairs,
+max over ranks (the reference times the whole cg.solve too: bp5/step-64.cu:442-463).  Prints ONE JSON line on rank 0.
+
+N > 1: one rank per GPU, RCCL over xGMI.  Either the caller starts the ranks (torch.distributed.run sets
+RANK/WORLD_SIZE), or this script starts them itself -- as a CHILD process, before anything here touches a GPU.
+Default = STRONG scaling: the SAME 116^3 problem split into N z-slabs (the reference reports the throughput of one
+~1e8-DoF problem spread over its ranks, bp5/step-64.cu:457-461); `--scaling weak` gives every rank a 116^3 slab.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +35,7 @@ def algorithmic_bytes_per_dof(p, n_cells, n_dofs, G=6, I=1, operator_only=False)
 
 def measured_traffic(key):
     """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
-    (profiles/*/traffic.json); None when this workload has not been profiled."""
+    (profiles/*/traffic.json, latest round wins); None when this workload has not been profiled."""
     best = None
     prof = os.path.join(ROOT, "profiles")
     for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
@@ -38,26 +43,43 @@ def measured_traffic(key):
         if os.path.exists(f):
             for e in json.load(open(f))["entries"]:
                 if e["key"] == key:
-                    best = e
+                    best = dict(e, source=f"profiles/{rnd}/traffic.json")
     return best
 
 
-def cpu_baseline(p, quad, cells, iters, deform, km):
-    """CPU restatement (oracle/bp5_oracle.c, OpenMP) timed on the host cores: a reported
-    baseline ("port"), not deal.II and not the optimisation target."""
+def cpu_baseline(mesh, p, quad, km, budget_s, max_iters):
+    """CPU restatement (oracle/bp5_oracle.c, OpenMP) timed on the host cores ON THE BENCH'S OWN MESH (same cells, same
+    DoF numbering, same coefficient): a reported baseline ("port"), not deal.II and not the optimisation target.
+    Bounded: one timed iteration sizes a plain-CG run of about `budget_s` seconds."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import bp5_oracle as O
     import c_oracle as CO
-    m = O.BrickMesh(p, cells, deform_amp=deform)
-    cp = CO.CProblem(p, quad, m.l2g, m.coords, m.constrained, km)
+    cp = CO.CProblem(p, quad, mesh.l2g, mesh.coords, mesh.constrained, km)
     b = cp.rhs()
+    t0 = time.perf_counter()
     cp.cg_plain(b, 1)
+    t1 = time.perf_counter() - t0
+    iters = int(max(2, min(max_iters, budget_s / max(t1, 1e-6))))
     t0 = time.perf_counter()
     _, k, _ = cp.cg_plain(b, iters)
     dt = time.perf_counter() - t0
-    return {"value": m.n_dofs * k / dt, "unit": "DoF/s", "cores": CO.lib().orc_num_threads(), "kind": "port",
-            "sample": f"CPU restatement (not deal.II): plain CG, p={p}, {cells[0]}x{cells[1]}x{cells[2]} cells, "
-                      f"{m.n_dofs} DoFs, {k} iterations, {dt:.1f} s"}
+    c = mesh.cells
+    return {"value": mesh.n_owned * k / dt, "unit": "DoF/s", "cores": CO.lib().orc_num_threads(), "kind": "port",
+            "sample": f"CPU restatement (not deal.II) on the bench's own mesh: plain CG, p={p}, {c[0]}x{c[1]}x{c[2]} cells, "
+                      f"{mesh.n_owned} DoFs, {k} iterations, {dt:.1f} s"}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run BEFORE this
+    process imports torch or touches a GPU (a process that has initialised the GPU must never be replaced), relay the
+    child's output and exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -66,7 +88,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree", type=int, default=4)
-    ap.add_argument("--cells", type=int, nargs=3, default=None, help="cells per direction PER GPU (default: ~1e8 DoFs)")
+    ap.add_argument("--cells", type=int, nargs=3, default=None,
+                    help="cells per direction of the WHOLE problem (strong scaling) / per GPU (weak scaling); default: config 3 / 4 sizes")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the same problem split into N z-slabs (default, BASELINE config 3); weak = one such problem per GPU")
     ap.add_argument("--quadrature", choices=["gauss", "gll"], default="gauss")
     ap.add_argument("--coefficient", choices=["one", "step64"], default="step64")
     ap.add_argument("--deform", type=float, default=0.0)
@@ -77,10 +102,17 @@ def main():
     ap.add_argument("--cell-block", type=int, nargs=3, default=None,
                     help="hand the cells over in bricks of this many cells (default: 4 4 4 at p=4 -> block-assembled kernel, 8 8 8 at p>=5; "
                          "0 0 0 = lexicographic cell order -> pencil kernel with atomics)")
+    ap.add_argument("--sustained-iters", type=int, default=200, help="reference protocol: iterations per repetition (bp5/step-64.cu:729); 0 = skip")
+    ap.add_argument("--sustained-reps", type=int, default=3, help="reference protocol: repetitions, best one reported (bp5/step-64.cu:457-463)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="host only (no GPU, no process group): every rank builds its slab of the mesh and prints its partition as one JSON line")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
     import bp5_pkg
     pkg = bp5_pkg.load()
 
@@ -89,9 +121,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    if not args.dry_run:
+        import torch
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not args.dry_run:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
@@ -100,8 +134,9 @@ def main():
     p = args.degree
     # p = 4: the headline size (config 3: 116^3 cells, 100 544 625 DoFs); other degrees: config 4 (~5e7 DoFs)
     n1 = {1: 367, 2: 184, 3: 122, 4: 116, 5: 73, 6: 61, 7: 52, 8: 46}[p]
-    cells_per_gpu = tuple(args.cells) if args.cells else (n1, n1, n1)
-    cells = (cells_per_gpu[0], cells_per_gpu[1], cells_per_gpu[2] * world)  # weak scaling: z-slabs
+    base = tuple(args.cells) if args.cells else (n1, n1, n1)
+    strong = args.scaling == "strong"
+    cells = base if strong else (base[0], base[1], base[2] * world)   # z-slabs either way
     quad = pkg.QUAD_GAUSS if args.quadrature == "gauss" else pkg.QUAD_GLL
     km = pkg.COEF_STEP64 if args.coefficient == "step64" else pkg.COEF_ONE
 
@@ -112,6 +147,11 @@ def main():
     blocked = all(b > 0 for b in block)
     mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world,
                          cell_block=block if blocked else (0, 0, 0), dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0)
+    if args.dry_run:
+        print(json.dumps({"rank": rank, "world": world, "scaling": args.scaling, "cells": list(cells), "n_cells": int(mesh.n_cells),
+                          "n_interior_cells": int(mesh.n_interior_cells), "n_owned": int(mesh.n_owned), "n_ghost": int(mesh.n_ghost),
+                          "n_global_dofs": int(mesh.n_global_dofs), "neighbors": [int(r) for r in mesh.neighbor_rank]}), flush=True)
+        return
     G = 6 if args.geometry == "merged6" else 1
     op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
                              geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
@@ -128,6 +168,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     # warm-up
     Solver(pkg.IterationNumberControl(max(args.warmup, 1), 0.0), profile=True).solve(op, x, b, precond)
     barrier()
@@ -137,15 +185,26 @@ def main():
     t0 = time.perf_counter()
     solver.solve(op, x, b, precond)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     iters = ctl.last_step()
     n_global = int(mesh.n_global_dofs)
     value = n_global * iters / dt
+
+    # the reference's own protocol (bp5/step-64.cu:443-463,724-730): solves of 200 iterations, wall clock + device sync
+    # around each, the BEST repetition is reported.  Minutes-long runs clock ~5 % below short bursts (profiles/r1 j_*).
+    sustained = None
+    if args.sustained_iters > 0 and args.sustained_reps > 0:
+        best, sctl = 0.0, pkg.IterationNumberControl(args.sustained_iters, 0.0)
+        ssolver = Solver(sctl)
+        for _ in range(args.sustained_reps):
+            barrier()
+            t0 = time.perf_counter()
+            ssolver.solve(op, x, b, precond)
+            barrier()
+            sdt = max_over_ranks(time.perf_counter() - t0)
+            best = max(best, n_global * sctl.last_step() / sdt)
+        sustained = {"value": best, "unit": "DoF/s", "iterations": args.sustained_iters, "repetitions": args.sustained_reps,
+                     "protocol": "reference: best of n repetitions of one solve, wall clock incl. device sync (bp5/step-64.cu:457-463,724-730)"}
 
     # achievable-stream figure: device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
     import ctypes as C
@@ -166,41 +225,49 @@ def main():
 
     if rank == 0:
         n_cells_local, n_dofs_local = mesh.n_cells, mesh.n_owned
+        r = n_cells_local * (p + 1) ** 3 / n_dofs_local
         B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
         B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
         achieved = B_op * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
         ev = op.mf_data.get_apply_variant()
-        key = f"p{p}_{args.quadrature}_{cells_per_gpu[0]}x{cells_per_gpu[1]}x{cells_per_gpu[2]}_{args.geometry}_v{ev}"
-        tr = measured_traffic(key) if args.deform == 0.0 else None
+        key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}"
+        tr = measured_traffic(key) if (args.deform == 0.0 and world == 1) else None
+        block_kernel = ev in (48, 49, 56)
         out = {
             "metric": "BP5 DoFs/sec per CG iter (p=4, ~1e8 DoFs) + % HBM roofline at 1/2/4/8 GPUs",
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": iters, "warmup": args.warmup,
-            "ms_per_step": dt / max(iters, 1) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / max(iters, 1) * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
-                       "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world}",
+                       "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world} ({args.scaling} scaling)",
                        "cell_block": list(block) if blocked else None, "apply_variant": ev},
             "value_per_gpu": value / world,   # the reference's convention divides by the rank count (bp5/step-64.cu:457-461)
             "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
                             "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS,
                             "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": value / world * B / 1e9 / stream_copy_gbs},
-            # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs) / average duration of the cell kernel
-            # (HIP events on the solver's stream around that launch, inside the timed solve); `operator_ms` is the whole
-            # application: zero-fill (atomic kernels) + cell kernel + combine pass (owner-scatter kernels); `traffic`: PMC bytes
+            # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs of this rank) / average duration of the cell
+            # kernel (HIP events on the solver's stream around that launch, inside the timed solve); `operator_ms` is the whole
+            # application: zero-fill (atomic kernels) + cell kernel + combine pass (owner-scatter kernels)
             "roofline": {"bound": "hbm", "kernel": tr["kernel"] if tr else {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: "apply_block_kernel<4,false,32,1,288768>"}.get(ev, f"apply variant {ev}"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": tr["traffic_bytes"] if tr else None, "algorithmic_bytes": B_op * n_dofs_local,
+                         "traffic": tr["traffic_bytes"] if tr else None,
+                         "traffic_source": (tr["source"] + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (not measured in this run)") if tr else None,
+                         "algorithmic_bytes": B_op * n_dofs_local,
                          "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
                          "operator_ms": ctl.operator_ms_avg,
-                         "algorithmic_formula": f"16 + I*4r + G*8r B/DoF with I=1, G={G} (SURVEY 8d)"
-                                                + ("; the block kernel's own index stream is 2r B/DoF (packed run/offset), local_to_global is not read" if ev == 56 else "")},
+                         "algorithmic_formula": f"16 + I*4r + G*8r B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)",
+                         # what this kernel has to move for its own index representation (the contract formula credits I = 1)
+                         "bytes_moved_formula": (f"16 + 2r + G*8r = {16 + 2 * r + G * 8 * r:.1f} B/DoF: the block kernel reads one packed u16 (run, offset) "
+                                                 f"per cell-local DoF instead of the 4r of local_to_global") if block_kernel else
+                                                f"16 + 4r + G*8r = {B_op:.1f} B/DoF (local_to_global is read)"},
         }
+        if sustained:
+            out["sustained"] = sustained
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            # bounded sample of the same workload family: ~10 s of host CPU work
-            out["cpu_baseline"] = cpu_baseline(p, quad, (48, 48, 48) if p <= 4 else (24, 24, 24), 120, args.deform, km)
+            out["cpu_baseline"] = cpu_baseline(mesh, p, quad, km, args.cpu_budget, max(args.steps, 2))
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

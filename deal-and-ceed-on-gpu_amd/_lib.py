@@ -30,7 +30,7 @@ def lib_path():
 def build(verbose=False):
     """Compile libbp5.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=out)
+    subprocess.check_call(["make", "-j8", "-C", os.path.join(_HERE, "csrc")], stdout=out)
     return lib_path()
 
 

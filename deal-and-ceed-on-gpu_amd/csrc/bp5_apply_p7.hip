@@ -1,0 +1,3 @@
+// fused-operator kernels of degree 7: instantiates the variant dispatch of bp5_device.hpp for this degree
+#include "bp5_device.hpp"
+template int apply_degree_impl<7>(bp5_mf *, const double *, const double *, double *, uint32_t, uint32_t, bool);

@@ -1,105 +1,7 @@
 // C-ABI implementation: MatrixFree handle, operator launches, BLAS-1, CG drivers, RCCL halo.
 // Every entry point cites the reference interface it replaces in include/bp5.h.
-#include "bp5_internal.hpp"
-#include "bp5_kernels.hpp"
+#include "bp5_device.hpp"
 
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <vector>
-
-using namespace bp5;
-
-#define HIP_TRY(expr)                                                                                              \
-  do {                                                                                                             \
-    hipError_t e_ = (expr);                                                                                        \
-    if (e_ != hipSuccess)                                                                                          \
-      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? BP5_ERR_NO_DEVICE : BP5_ERR_HIP,         \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                                              \
-  } while (0)
-#define NCCL_TRY(expr)                                                                                             \
-  do {                                                                                                             \
-    ncclResult_t r_ = (expr);                                                                                      \
-    if (r_ != ncclSuccess) return fail(BP5_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));         \
-  } while (0)
-#define BP5_TRY(expr)                                                                                              \
-  do {                                                                                                             \
-    int s_ = (expr);                                                                                               \
-    if (s_ != BP5_OK) return s_;                                                                                   \
-  } while (0)
-#define KERNEL_CHECK() HIP_TRY(hipGetLastError())
-
-struct bp5_comm {
-  ncclComm_t comm = nullptr;
-  int rank = 0, n_ranks = 1;
-};
-struct bp5_event {
-  hipEvent_t ev = nullptr;
-};
-
-struct bp5_mf {
-  int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
-  uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
-  int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
-  uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
-  bool combine_csr = false; // A/B: per-DoF CSR combine kernel instead of the run-length one
-  int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
-  int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
-  double *d_scalar_plane = nullptr, *d_gcell = nullptr;
-  bool force_atomic_scatter = false, block_shared_atomic = false;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  Tables tab, tab_gauss;
-  // device arrays
-  uint32_t *d_l2g = nullptr, *d_constrained = nullptr, *d_send_idx = nullptr;
-  double *d_coords = nullptr, *d_tab = nullptr, *d_tab_gauss = nullptr;
-  // Data mirror (lazy)
-  uint32_t *d_l2g_padded = nullptr, *d_constraint_mask = nullptr;
-  double *d_inv_jac = nullptr, *d_JxW = nullptr, *d_qpoints = nullptr;
-  uint32_t pad = 0;
-  // halo plan
-  std::vector<int> neighbors;
-  std::vector<uint32_t> send_off, recv_off;
-  double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
-  bp5_comm *comm = nullptr;
-  // solver workspace
-  double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
-  int *d_st = nullptr;
-  double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr, *d_evec = nullptr;
-  char *ws_base = nullptr;
-  unsigned long long *d_stamps = nullptr;
-  double *h_sc = nullptr; // pinned
-  int *h_st = nullptr;    // pinned
-  std::vector<hipEvent_t> ev_pool;
-  hipEvent_t prof_mark = nullptr; // profiling: recorded once before the combine pass (= end of the dominant kernel)
-  // team plans of the team-assembled kernel, keyed by cells per team
-  std::vector<uint32_t> h_l2g;
-  struct DevPlan {
-    uint32_t *off = nullptr, *dofs = nullptr, *sh_dof = nullptr, *sh_off = nullptr, *sh_slot = nullptr;
-    uint16_t *pos = nullptr;
-    uint8_t *cell_round = nullptr, *team_rounds = nullptr;
-    double *partial = nullptr;
-    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
-    uint16_t *packed = nullptr;
-    std::vector<double> h_cost;                       // [n_groups+1] prefix sum of the estimated cost of the blocks (pass units)
-    uint32_t *wg_block = nullptr;                     // cached ranges for (wg_n, wg_b0, wg_b1)
-    uint32_t wg_n = 0, wg_b0 = 0, wg_b1 = 0;
-    uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
-    uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
-    bool covers_all = false;
-  };
-  std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
-  struct DevMarch { uint32_t *team_off = nullptr, *entries = nullptr; uint32_t n_teams = 0; };
-  std::map<int, DevMarch> march_plans; // keyed by cells per team
-  std::map<int, DevPlan> plans;
-  size_t n_local() const { return (size_t)n_owned + n_ghost; }
-};
 
 // ------------------------------------------------------------------------------------ device / vectors
 extern "C" int bp5_device_count(int *count)
@@ -116,6 +18,7 @@ extern "C" int bp5_vec_alloc(size_t n, double **out)
   if (!out) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipMalloc((void **)out, std::max<size_t>(n, 1) * sizeof(double)));
   HIP_TRY(hipMemset(*out, 0, std::max<size_t>(n, 1) * sizeof(double)));
+  HIP_TRY(hipStreamSynchronize(nullptr)); // the fill runs on the null stream; callers use it on (possibly non-blocking) streams
   return BP5_OK;
 }
 extern "C" int bp5_vec_free(double *v) { HIP_TRY(hipFree(v)); return BP5_OK; }
@@ -123,13 +26,6 @@ extern "C" int bp5_copy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(
 extern "C" int bp5_copy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return BP5_OK; }
 
 // ------------------------------------------------------------------------------------ create / destroy
-template <typename T>
-static int upload(T **dptr, const T *host, size_t count)
-{
-  HIP_TRY(hipMalloc((void **)dptr, std::max<size_t>(count, 1) * sizeof(T)));
-  if (count) HIP_TRY(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
-  return BP5_OK;
-}
 static void pack_tab(const Tables &t, std::vector<double> &v)
 {
   const int n = t.n;
@@ -154,6 +50,10 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   if (d->device < 0 || d->device >= ndev) return fail(BP5_ERR_INVALID, "bad device ordinal");
   HIP_TRY(hipSetDevice(d->device));
   bp5_mf *mf = new bp5_mf;
+  struct Guard { // every early return below releases the handle and whatever has been uploaded so far
+    bp5_mf *m;
+    ~Guard() { if (m) bp5_mf_destroy(m); }
+  } guard{mf};
   mf->degree = d->degree; mf->quadrature = d->quadrature; mf->coefficient = d->coefficient;
   mf->n = d->degree + 1; mf->n3 = mf->n * mf->n * mf->n; mf->device = d->device;
   mf->n_cells = d->n_cells; mf->n_interior = d->n_interior_cells; mf->n_owned = d->n_owned; mf->n_ghost = d->n_ghost;
@@ -162,9 +62,9 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   // validate indices on the host: a bad index would fault on the GPU
   const size_t nl = (size_t)d->n_cells * mf->n3, nloc = mf->n_local();
   for (size_t s = 0; s < nl; ++s)
-    if (d->local_to_global_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "local_to_global entry out of range"); }
+    if (d->local_to_global_host[s] >= nloc) { return fail(BP5_ERR_INVALID, "local_to_global entry out of range"); }
   for (uint32_t s = 0; s < d->n_constrained; ++s)
-    if (d->constrained_host[s] >= nloc) { delete mf; return fail(BP5_ERR_INVALID, "constrained index out of range"); }
+    if (d->constrained_host[s] >= nloc) { return fail(BP5_ERR_INVALID, "constrained index out of range"); }
   mf->stream = (hipStream_t)d->stream; // NULL == the HIP default stream (ordered with the host's other default-stream work)
   BP5_TRY(upload(&mf->d_l2g, d->local_to_global_host, nl));
   mf->h_l2g.assign(d->local_to_global_host, d->local_to_global_host + nl);
@@ -172,7 +72,7 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     const uint32_t *o = d->cell_block_offsets_host;
     bool ok = o[0] == 0 && o[d->n_cell_blocks] == d->n_cells;
     for (uint32_t b = 0; ok && b < d->n_cell_blocks; ++b) ok = o[b] < o[b + 1];
-    if (!ok) { delete mf; return fail(BP5_ERR_INVALID, "cell_block_offsets must ascend from 0 to n_cells"); }
+    if (!ok) { return fail(BP5_ERR_INVALID, "cell_block_offsets must ascend from 0 to n_cells"); }
     mf->h_block_off.assign(o, o + d->n_cell_blocks + 1);
   }
   BP5_TRY(upload(&mf->d_coords, d->node_coords_host, nloc * 3));
@@ -182,18 +82,18 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   pack_tab(tabg, tv); BP5_TRY(upload(&mf->d_tab_gauss, tv.data(), tv.size()));
   // halo plan
   if (d->n_neighbors > 0) {
-    if (!d->neighbor_rank_host || !d->send_offsets_host || !d->recv_offsets_host) { delete mf; return fail(BP5_ERR_INVALID, "halo plan arrays missing"); }
+    if (!d->neighbor_rank_host || !d->send_offsets_host || !d->recv_offsets_host) { return fail(BP5_ERR_INVALID, "halo plan arrays missing"); }
     mf->neighbors.assign(d->neighbor_rank_host, d->neighbor_rank_host + d->n_neighbors);
     mf->send_off.assign(d->send_offsets_host, d->send_offsets_host + d->n_neighbors + 1);
     mf->recv_off.assign(d->recv_offsets_host, d->recv_offsets_host + d->n_neighbors + 1);
     const uint32_t ns = mf->send_off.back();
-    if (mf->recv_off.back() != d->n_ghost) { delete mf; return fail(BP5_ERR_INVALID, "recv ranges must cover the ghost range"); }
+    if (mf->recv_off.back() != d->n_ghost) { return fail(BP5_ERR_INVALID, "recv ranges must cover the ghost range"); }
     for (uint32_t s = 0; s < ns; ++s)
-      if (d->send_indices_host[s] >= d->n_owned) { delete mf; return fail(BP5_ERR_INVALID, "send index out of owned range"); }
+      if (d->send_indices_host[s] >= d->n_owned) { return fail(BP5_ERR_INVALID, "send index out of owned range"); }
     BP5_TRY(upload(&mf->d_send_idx, d->send_indices_host, ns));
     HIP_TRY(hipMalloc((void **)&mf->d_sendbuf, std::max<size_t>(ns, 1) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&mf->d_recvbuf, std::max<size_t>(ns, 1) * sizeof(double)));
-  } else if (d->n_ghost) { delete mf; return fail(BP5_ERR_INVALID, "ghosts without a halo plan"); }
+  } else if (d->n_ghost) { return fail(BP5_ERR_INVALID, "ghosts without a halo plan"); }
   // solver workspace
   HIP_TRY(hipMalloc((void **)&mf->d_partials, 8 * MAXBLK * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&mf->d_sc, SC_COUNT * sizeof(double)));
@@ -201,8 +101,12 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   HIP_TRY(hipMalloc((void **)&mf->d_st, ST_COUNT * sizeof(int)));
   HIP_TRY(hipMemset(mf->d_sc, 0, SC_COUNT * sizeof(double)));
   HIP_TRY(hipMemset(mf->d_st, 0, ST_COUNT * sizeof(int)));
+  HIP_TRY(hipStreamSynchronize(nullptr)); // null-stream fills must not race with work on a non-blocking handle stream
   HIP_TRY(hipHostMalloc((void **)&mf->h_sc, SC_COUNT * sizeof(double)));
   HIP_TRY(hipHostMalloc((void **)&mf->h_st, ST_COUNT * sizeof(int)));
+  HIP_TRY(hipEventCreate(&mf->ev_solve[0]));
+  HIP_TRY(hipEventCreate(&mf->ev_solve[1]));
+  guard.m = nullptr;
   *out = mf;
   return BP5_OK;
 }
@@ -219,6 +123,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
   for (hipEvent_t e : mf->ev_pool) hipEventDestroy(e);
+  for (hipEvent_t e : mf->ev_solve) if (e) hipEventDestroy(e);
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
@@ -248,9 +153,29 @@ extern "C" int bp5_mf_coef_size(const bp5_mf *mf, size_t *n)
   *n = (size_t)6 * mf->n_cells * mf->n3;
   return BP5_OK;
 }
+// the variants of the product library: every one of them computes the operator (they differ in launch shape, staging and
+// scatter strategy).  The timing-only ablation builds (wrong results by construction) exist only in libbp5_timing.so
+// (make timing, -DBP5_TIMING_BUILDS; used by tools/bench_apply.py) and are refused here.
+static bool product_variant(int degree, int v)
+{
+  if (v == 0) return true;
+  if (v >= 100) return v < 200 && product_variant(degree, v - 100) && v - 100 >= 10 && v - 100 <= 14; // team kernel, atomic scatter
+  if (v == 10 || v == 50 || v == 70) return true;
+  switch (degree) {
+    case 1: case 3: return v == 1;
+    case 4: return (v >= 1 && v <= 6) || (v >= 11 && v <= 14) || (v >= 48 && v <= 59) || v == 71 || v == 72;
+    case 5: return v >= 1 && v <= 3;
+    case 6: return v >= 1 && v <= 5;
+    case 7: case 8: return (v >= 1 && v <= 3) || v == 5;
+  }
+  return false;
+}
 extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
 {
   if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+#ifndef BP5_TIMING_BUILDS
+  if (!product_variant(mf->degree, v)) return fail(BP5_ERR_INVALID, "unknown (degree, apply variant): timing-only builds live in libbp5_timing.so");
+#endif
   mf->apply_variant = v;
   return BP5_OK;
 }
@@ -262,7 +187,6 @@ extern "C" int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups)
   mf->block_max_wg = max_workgroups;
   return BP5_OK;
 }
-static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block = 64);
 extern "C" int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, int *packed_indices)
 {
   if (!mf || !n_blocks || !max_runs || !packed_indices) return fail(BP5_ERR_INVALID, "null argument");
@@ -403,33 +327,10 @@ extern "C" int bp5_mf_get_data(bp5_mf *mf, int color, bp5_mf_data *out)
 }
 
 // ------------------------------------------------------------------------------------ operator
-template <int P, bool COLL, int TW, int LPC, int TPB, bool PF, int ABL = 0>
-static int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
-{
-  constexpr int n = P + 1;
-  constexpr int CPT = 64 * TW / LPC;
-  using L = LdsLayout<n, LPC>;
-  ApplyArgs a{};
-  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
-  a.cell_begin = c0; a.cell_end = c1;
-  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
-  a.n_teams = (c1 - c0 + CPT - 1) / CPT;
-  const uint32_t nblk = (a.n_teams + TPB - 1) / TPB;
-  a.teams_per_xcd = (nblk + 7) / 8;
-  ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
-  const size_t lds = (size_t)TPB * CPT * L::CS * sizeof(double);
-  hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF, ABL>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
-                     sh);
-  KERNEL_CHECK();
-  return BP5_OK;
-}
 
 // key > 0: uniform teams of `key` cells (team kernel); key < 0: cell blocks walked in passes of
 // -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
-static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
+int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
 {
   auto it = mf->plans.find(key);
   if (it == mf->plans.end()) {
@@ -500,7 +401,7 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
     BP5_TRY(upload(&dp.sh_off, h.sh_off.data(), h.sh_off.size()));
     BP5_TRY(upload(&dp.sh_slot, h.sh_slot.data(), h.sh_slot.size()));
     HIP_TRY(hipMalloc((void **)&dp.partial, std::max<size_t>(h.dofs.size(), 1) * sizeof(double)));
-    HIP_TRY(hipMemset(dp.partial, 0, std::max<size_t>(h.dofs.size(), 1) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(dp.partial, 0, std::max<size_t>(h.dofs.size(), 1) * sizeof(double), mf->stream)); // on the handle's stream (bp5.h:14)
     BP5_TRY(upload(&dp.cell_off, h.group_cell_off.data(), h.group_cell_off.size()));
     if (key < 0) {
       BP5_TRY(upload(&dp.pass_cell, h.pass_cell.data(), h.pass_cell.size()));
@@ -558,7 +459,7 @@ static int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_
   *dpo = &it->second;
   return BP5_OK;
 }
-static int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
+int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
 {
   bp5_mf::DevPlan *q = nullptr;
   BP5_TRY(get_plan_raw(mf, cpt, &q));
@@ -567,7 +468,7 @@ static int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
   return BP5_OK;
 }
 
-static int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
+int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
 {
   if (!dp->n_shared) return BP5_OK;
   if (mf->prof_mark) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
@@ -585,214 +486,8 @@ static int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set
   return BP5_OK;
 }
 
-// block-assembled kernel; falls back to the team kernel path when the range is partial
-template <int P, bool COLL, int LPC, int ABL = 0>
-static int launch_block_t(bp5_mf *mf, const double *coef, const double *src, double *dst, bool overwrite)
-{
-  constexpr int n = P + 1;
-  constexpr int CPT = 256 / LPC;
-  using L = LdsLayout<n, LPC>;
-  bp5_mf::DevPlan *dp = nullptr;
-  BP5_TRY(get_plan_raw(mf, -CPT, &dp));
-  const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
-  const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
-  if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
-  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 64 runs per block: packed indices unavailable");
-  if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
-  BlockPlan bp{}; // value-initialised: a field this launcher forgets is null, not garbage
-  bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;
-  bp.packed = dp->packed;
-  bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
-  bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
-  // a block-aligned cell range: only these blocks run, accumulate mode; DoFs shared with other blocks go to dst by
-  // atomics (the partial slab + combine pass needs every block of the plan in the launch)
-  const bool sub_range = mf->blk_b1 > mf->blk_b0 && (mf->blk_b0 != 0 || mf->blk_b1 != dp->n_groups);
-  bp.blk_begin = sub_range ? mf->blk_b0 : 0;
-  if (sub_range) bp.n_blocks = mf->blk_b1 - mf->blk_b0;
-  if (sub_range && overwrite) return fail(BP5_ERR_INVALID, "a cell range cannot overwrite dst");
-  // persistent grid: two workgroups per CU (LDS budget), a multiple of 8 for the XCD mapping
-  if (!mf->n_cus) {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
-    mf->n_cus = prop.multiProcessorCount;
-  }
-  const int wg_per_cu = ((ABL & 2048) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1;
-  uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
-  if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
-  n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
-  bp.n_wg = n_wg;
-  { // block ranges of the persistent workgroups: equal shares of the estimated COST (thin or partial bricks are cheaper per
-    // block but dearer per cell than full ones), cached
-    const uint32_t B0 = bp.blk_begin, B1 = bp.blk_begin + bp.n_blocks;
-    if (!dp->wg_block || dp->wg_n != n_wg || dp->wg_b0 != B0 || dp->wg_b1 != B1) {
-      std::vector<uint32_t> wb(n_wg + 1);
-      const std::vector<double> &pc = dp->h_cost;
-      const double c0 = pc[B0], total = pc[B1] - c0;
-      for (uint32_t w = 0; w <= n_wg; ++w)
-        wb[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + B1 + 1, c0 + total * w / n_wg - 1e-9) - pc.begin());
-      wb[0] = B0; wb[n_wg] = B1;
-      if (dp->wg_block) { HIP_TRY(hipStreamSynchronize(mf->stream)); HIP_TRY(hipFree(dp->wg_block)); dp->wg_block = nullptr; }
-      BP5_TRY(upload(&dp->wg_block, wb.data(), wb.size()));
-      dp->wg_n = n_wg; dp->wg_b0 = B0; dp->wg_b1 = B1;
-    }
-    bp.wg_block = dp->wg_block;
-  }
-  bp.stamps = nullptr;
-  if (ABL & 4096) {
-    if (!mf->d_stamps) HIP_TRY(hipMalloc((void **)&mf->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(mf->d_stamps, 0, 4096 * 16 * sizeof(unsigned long long), mf->stream));
-    bp.stamps = mf->d_stamps;
-  }
-  ApplyArgs a{};
-  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
-  a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
-  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
-  ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
-  const bool set = overwrite && dp->covers_all;
-  if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-  const dim3 grid(n_wg), block(256);
-  if (mf->block_shared_atomic || sub_range) {
-    // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
-    if (set && dp->n_shared) {
-      hipLaunchKernelGGL(zero_indexed_kernel, dim3((dp->n_shared + 255) / 256), dim3(256), 0, mf->stream, dp->sh_dof, dp->n_shared, dst);
-      KERNEL_CHECK();
-    }
-    if (set) {
-      auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET_ATOMIC, ABL>;
-      HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
-    } else {
-      auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD_ATOMIC, ABL>;
-      HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
-    }
-    KERNEL_CHECK();
-    return BP5_OK;
-  }
-  if (set) {
-    auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET, ABL>;
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
-  } else {
-    auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD, ABL>;
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
-  }
-  KERNEL_CHECK();
-  if (ABL & 4096) { // diagnostic build: print the per-phase cycle shares (never quote its run time)
-    HIP_TRY(hipStreamSynchronize(mf->stream));
-    std::vector<unsigned long long> hs((size_t)n_wg * 16);
-    HIP_TRY(hipMemcpy(hs.data(), mf->d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double tot[9] = {0};
-    for (uint32_t w = 0; w < n_wg; ++w) for (int k = 0; k < 9; ++k) tot[k] += (double)hs[(size_t)w * 16 + k];
-    double all = 0; for (int k = 0; k < 7; ++k) all += tot[k];
-    static const char *nm[7] = {"issue loads", "evaluate (+wait u)", "wait idx + issue gather", "q-op (+wait metric)", "integrate", "accumulate", "block boundary"};
-    fprintf(stderr, "[bp5 stamps] passes/wg %.1f, cycles/pass %.0f\n", tot[8] / n_wg, all / tot[8]);
-    for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
-  }
-  if (ABL & 1023) return BP5_OK; // (1024 and above are real modes) timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
-  return launch_combine(mf, dp, dst, set);
-}
-
-// overwrite == true: dst need not be zeroed by the caller, the launch defines every entry
-template <int P, bool COLL, int TW, int LPC, bool PF, int OPT = 0>
-static int launch_team_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
-{
-  constexpr int n = P + 1;
-  constexpr int CPT = 64 * TW / LPC;
-  using L = LdsLayout<n, LPC>;
-  TeamPlan tp{};
-  bp5_mf::DevPlan *dp = nullptr;
-  BP5_TRY(get_plan(mf, CPT, tp, &dp));
-  ApplyArgs a{};
-  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
-  a.cell_begin = c0; a.cell_end = c1;
-  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
-  a.n_teams = (c1 + CPT - 1) / CPT - c0 / CPT;
-  a.teams_per_xcd = (a.n_teams + 7) / 8;
-  ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
-  const size_t lds = (size_t)CPT * L::CS * sizeof(double);
-  const dim3 grid(a.teams_per_xcd * 8), block(64 * TW);
-  const bool whole = (c0 == 0 && c1 == mf->n_cells);
-  if (!whole || mf->force_atomic_scatter) {
-    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-    hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_ATOMIC, OPT>), grid, block, lds, mf->stream, a, tp, sh);
-  } else {
-    const bool set = overwrite && dp->covers_all;
-    if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-    if (set) hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_SET, OPT>), grid, block, lds, mf->stream, a, tp, sh);
-    else hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_ADD, OPT>), grid, block, lds, mf->stream, a, tp, sh);
-    KERNEL_CHECK();
-    return launch_combine(mf, dp, dst, set);
-  }
-  KERNEL_CHECK();
-  return BP5_OK;
-}
-#define TEAM_CASE(P, V, TW, LPC, PF)                                                                               \
-  case (P)*100 + (V):                                                                                              \
-    return coll ? launch_team_t<P, true, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)                       \
-                : launch_team_t<P, false, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)
-
-// z-marching kernel (whole cell range only; partial ranges take the plain pencil kernel)
-template <int P, bool COLL, int TW, int LPC, bool PF, int ABL = 0>
-static int launch_march_t(bp5_mf *mf, const double *coef, const double *src, double *dst)
-{
-  constexpr int n = P + 1;
-  constexpr int CPT = 64 * TW / LPC;
-  using L = LdsLayout<n, LPC>;
-  auto it = mf->march_plans.find(CPT);
-  if (it == mf->march_plans.end()) {
-    MarchPlanHost h;
-    BP5_TRY(build_march_plan(mf->h_l2g.data(), mf->n_cells, n, CPT, mf->march_max_steps, h));
-    bp5_mf::DevMarch dm;
-    BP5_TRY(upload(&dm.team_off, h.team_off.data(), h.team_off.size()));
-    BP5_TRY(upload(&dm.entries, h.entries.data(), h.entries.size()));
-    dm.n_teams = (uint32_t)h.team_off.size() - 1;
-    it = mf->march_plans.emplace(CPT, dm).first;
-  }
-  MarchPlan mp{};
-  mp.team_off = it->second.team_off; mp.entries = it->second.entries; mp.n_teams = it->second.n_teams;
-  mp.teams_per_xcd = (mp.n_teams + 7) / 8;
-  ApplyArgs a{};
-  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
-  a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = mp.n_teams; a.teams_per_xcd = mp.teams_per_xcd;
-  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
-  ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
-  const size_t lds = (size_t)CPT * L::CS * sizeof(double);
-  hipLaunchKernelGGL((apply_march_kernel<P, COLL, TW, LPC, PF, ABL>), dim3(mp.teams_per_xcd * 8), dim3(64 * TW), lds, mf->stream, a, mp, sh);
-  KERNEL_CHECK();
-  return BP5_OK;
-}
-
-// variant table: (degree, variant) -> (TW, LPC, TPB, PF); variant 0 = default for the degree
-#define APPLY_CASE(P, V, TW, LPC, TPB, PF)                                                                         \
-  case (P)*100 + (V):                                                                                              \
-    if (overwrite && hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream) != hipSuccess)             \
-      return fail(BP5_ERR_HIP, "hipMemsetAsync");                                                                  \
-    return coll ? launch_apply_t<P, true, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)                            \
-                : launch_apply_t<P, false, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)
-
-// overwrite: the launch must leave dst = A src (no prior zeroing by the caller); otherwise dst += A src
-template <int P>
-static int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0, uint32_t c1)
-{ // TW = 4 teams when n^2 lanes per cell pack well into 256 threads, as for the 6-plane default
-  constexpr int n2 = (P + 1) * (P + 1);
-  constexpr int LPC = n2;
-  constexpr bool PF = true;
-  return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<P, true, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1)
-                                        : launch_apply_t<P, false, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1);
-}
 // [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
-static bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1)
+bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1)
 {
   const auto &o = mf->h_block_off;
   if (o.empty() || c1 <= c0) return false;
@@ -809,7 +504,14 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 {
   const int v = mf->apply_variant;
   if (v != 0) return v;
-  if (mf->degree == 1 || mf->degree == 3) return mf->geometry_mode == BP5_GEOM_AFFINE ? 0 : 10;
+  if (mf->degree == 1 || mf->degree == 3) {
+    if (mf->geometry_mode == BP5_GEOM_AFFINE) return 0;
+    if (mf->auto_team < 0) { // an irregular cell order can exhaust the team plan's rounds: then the atomic pencil kernel
+      bp5_mf::DevPlan *dp = nullptr;
+      mf->auto_team = get_plan_raw(mf, mf->degree == 1 ? 64 : 16, &dp) == BP5_OK;
+    }
+    return mf->auto_team ? 10 : 0;
+  }
   if (mf->degree != 4) return 0;
   const int fallback = mf->geometry_mode == BP5_GEOM_AFFINE ? 10 : 0; // affine: team kernel, else pencil kernel
   uint32_t b0_, b1_;
@@ -846,224 +548,17 @@ static bool variant_overwrites(const bp5_mf *mf, int ev)
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
 {
-  if (mf->geometry_mode == BP5_GEOM_AFFINE && c1 > c0) {
-    const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
-    const bool whole = c0 == 0 && c1 == mf->n_cells;
-    if (mf->degree == 4 && mf->apply_variant % 100 == 10) {
-      mf->force_atomic_scatter = mf->apply_variant >= 100;
-      return coll_ ? launch_team_t<4, true, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite)
-                   : launch_team_t<4, false, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite);
-    }
-    if (mf->degree == 4 && mf->apply_variant == 56) { // the default block-kernel shape on the scalar plane + per-cell K K^T
-      if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
-      struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
-      return coll_ ? launch_block_t<4, true, 32, 1024 + 2048 + 8192 + 16384 + 262144>(mf, mf->d_scalar_plane, src, dst, overwrite)
-                   : launch_block_t<4, false, 32, 1024 + 2048 + 8192 + 16384 + 262144>(mf, mf->d_scalar_plane, src, dst, overwrite);
-    }
-    if (mf->degree == 4 && whole && (mf->apply_variant == 54 || mf->apply_variant == 55)) {
-      mf->block_shared_atomic = true;
-      const int st_ = mf->apply_variant == 54 ? (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
-                                                       : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
-                                              : (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
-                                                       : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
-      mf->block_shared_atomic = false;
-      return st_;
-    }
-    if (mf->degree == 4 && whole && (mf->apply_variant == 50 || mf->apply_variant == 51))
-      return mf->apply_variant == 50 ? (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
-                                              : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
-                                     : (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
-                                              : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
-    if (mf->degree == 4 && mf->apply_variant == 85) // timing only: affine, no scatter atomics -> compute/latency floor of the pencil kernel
-      return launch_apply_t<4, false, 4, 25, 1, true, 1025>(mf, mf->d_scalar_plane, src, dst, c0, c1);
-    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-    switch (mf->degree) {
-      case 1: return launch_affine<1>(mf, src, dst, c0, c1);
-      case 2: return launch_affine<2>(mf, src, dst, c0, c1);
-      case 3: return launch_affine<3>(mf, src, dst, c0, c1);
-      case 4: return launch_affine<4>(mf, src, dst, c0, c1);
-      case 5: return launch_affine<5>(mf, src, dst, c0, c1);
-      case 6: return launch_affine<6>(mf, src, dst, c0, c1);
-      case 7: return launch_affine<7>(mf, src, dst, c0, c1);
-      case 8: return launch_affine<8>(mf, src, dst, c0, c1);
-    }
+  switch (mf->degree) {
+    case 1: return apply_degree_impl<1>(mf, coef, src, dst, c0, c1, overwrite);
+    case 2: return apply_degree_impl<2>(mf, coef, src, dst, c0, c1, overwrite);
+    case 3: return apply_degree_impl<3>(mf, coef, src, dst, c0, c1, overwrite);
+    case 4: return apply_degree_impl<4>(mf, coef, src, dst, c0, c1, overwrite);
+    case 5: return apply_degree_impl<5>(mf, coef, src, dst, c0, c1, overwrite);
+    case 6: return apply_degree_impl<6>(mf, coef, src, dst, c0, c1, overwrite);
+    case 7: return apply_degree_impl<7>(mf, coef, src, dst, c0, c1, overwrite);
+    case 8: return apply_degree_impl<8>(mf, coef, src, dst, c0, c1, overwrite);
   }
-  if (c1 <= c0) {
-    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
-    return BP5_OK;
-  }
-  const bool coll = mf->quadrature == BP5_QUAD_GLL;
-  // variants >= 100: the team kernel of (variant - 100) with the global-atomic scatter (A/B tests)
-  mf->force_atomic_scatter = mf->apply_variant >= 100;
-  int variant = mf->apply_variant % 100;
-  switch (mf->degree * 100 + variant) {
-    APPLY_CASE(1, 0, 1, 4, 4, true);
-    APPLY_CASE(1, 1, 1, 4, 4, true);
-    APPLY_CASE(2, 0, 1, 9, 4, true);
-    APPLY_CASE(3, 0, 1, 16, 4, true);
-    APPLY_CASE(3, 1, 1, 16, 4, true);
-    APPLY_CASE(4, 0, 4, 25, 1, true);
-    APPLY_CASE(4, 6, 1, 25, 4, true);
-    APPLY_CASE(4, 1, 1, 32, 4, true);
-    APPLY_CASE(4, 2, 2, 25, 1, true);
-    APPLY_CASE(4, 3, 4, 25, 1, true);
-    APPLY_CASE(4, 4, 1, 25, 1, true);
-    APPLY_CASE(4, 5, 1, 25, 4, false);
-    APPLY_CASE(5, 0, 4, 36, 1, true);
-    APPLY_CASE(5, 1, 1, 36, 4, true);
-    APPLY_CASE(5, 2, 4, 36, 1, false);
-    APPLY_CASE(5, 3, 2, 36, 1, true);
-    APPLY_CASE(6, 0, 4, 49, 1, true);   // defaults for p >= 6 from the high-degree sweep: prefetch all planes
-    APPLY_CASE(6, 5, 4, 49, 1, false);
-    APPLY_CASE(6, 1, 1, 49, 4, false);
-    APPLY_CASE(6, 2, 4, 49, 1, true);
-    APPLY_CASE(6, 3, 1, 49, 1, true);
-    APPLY_CASE(6, 4, 2, 49, 1, false);
-    APPLY_CASE(7, 0, 4, 64, 1, true);
-    APPLY_CASE(7, 5, 1, 64, 4, false);
-    APPLY_CASE(7, 1, 4, 64, 1, false);
-    APPLY_CASE(7, 2, 4, 64, 1, true);
-    APPLY_CASE(7, 3, 1, 64, 1, true);
-    APPLY_CASE(8, 0, 4, 81, 1, true);
-    APPLY_CASE(8, 5, 4, 81, 1, false);
-    APPLY_CASE(8, 1, 2, 81, 1, false);
-    APPLY_CASE(8, 2, 4, 81, 1, true);
-    APPLY_CASE(8, 3, 2, 81, 1, true);
-    // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
-#define ABL_CASE(M) case 400 + 20 + (M): return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
-    case 407: return coll ? launch_apply_t<4, true, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1);
-    case 408: return coll ? launch_apply_t<4, true, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
-    case 409: return coll ? launch_apply_t<4, true, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
-    case 482: return launch_apply_t<4, false, 4, 25, 1, true, 257>(mf, coef, src, dst, c0, c1);
-    case 483: return launch_apply_t<4, false, 4, 25, 1, true, 4096>(mf, coef, src, dst, c0, c1);
-    case 484: return launch_apply_t<4, false, 4, 25, 1, true, 8192>(mf, coef, src, dst, c0, c1);
-    case 480: return launch_apply_t<4, false, 4, 25, 1, true, 64>(mf, coef, src, dst, c0, c1);
-    case 481: { // E-vector stores need a big scratch target
-      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
-      return launch_apply_t<4, false, 4, 25, 1, true, 128>(mf, coef, src, mf->d_evec, c0, c1); }
-    case 490: {
-      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, ((size_t)mf->n_cells * mf->n3 + 4096 * 5) * sizeof(double) * 2));
-      return launch_apply_t<4, false, 4, 25, 1, true, 262144>(mf, coef, src, mf->d_evec, c0, c1); }
-    case 488: {
-      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
-      return launch_apply_t<4, false, 4, 25, 1, true, 128 + 65536>(mf, coef, src, mf->d_evec, c0, c1); }
-    case 489: {
-      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
-      return launch_apply_t<4, false, 4, 25, 1, true, 1 + 131072>(mf, coef, src, mf->d_evec, c0, c1); }
-    case 486: {
-      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
-      return launch_apply_t<4, false, 4, 25, 1, true, 128 + 16384>(mf, coef, src, mf->d_evec, c0, c1); }
-    ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(5); ABL_CASE(7); ABL_CASE(8); ABL_CASE(9); ABL_CASE(15); ABL_CASE(14); ABL_CASE(13); ABL_CASE(11);
-    // z-marching kernel, variants 70+ (atomic scatter: dst must be zero-filled like for the pencil kernel)
-#define MARCH_CASE(P, V, TW, LPC, PF)                                                                              \
-  case (P)*100 + (V):                                                                                              \
-    if (overwrite && hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream) != hipSuccess)             \
-      return fail(BP5_ERR_HIP, "hipMemsetAsync");                                                                  \
-    if (c0 != 0 || c1 != mf->n_cells)                                                                              \
-      return coll ? launch_apply_t<P, true, TW, LPC, 1, PF>(mf, coef, src, dst, c0, c1)                            \
-                  : launch_apply_t<P, false, TW, LPC, 1, PF>(mf, coef, src, dst, c0, c1);                          \
-    return coll ? launch_march_t<P, true, TW, LPC, PF>(mf, coef, src, dst) : launch_march_t<P, false, TW, LPC, PF>(mf, coef, src, dst)
-    case 473: return launch_march_t<4, false, 4, 25, true, 1>(mf, coef, src, dst); // timing only: march, no scatter
-    MARCH_CASE(1, 70, 4, 4, true);
-    MARCH_CASE(2, 70, 4, 9, true);
-    MARCH_CASE(3, 70, 4, 16, true);
-    MARCH_CASE(4, 70, 4, 25, true);
-    MARCH_CASE(4, 71, 2, 25, true);
-    MARCH_CASE(4, 72, 1, 25, true);
-    MARCH_CASE(5, 70, 4, 36, true);
-    MARCH_CASE(6, 70, 4, 49, true);
-    MARCH_CASE(7, 70, 4, 64, true);
-    MARCH_CASE(8, 70, 4, 81, true);
-    // block-assembled kernel (compact cell blocks, LDS accumulator, no atomics), variants 50+;
-    // a partial cell range cannot use the owner scatter and takes the atomic team kernel instead
-#define BLOCK_CASE(P, V, LPC, TW_FALLBACK, PF)                                                                     \
-  case (P)*100 + (V):                                                                                              \
-    if (c0 != 0 || c1 != mf->n_cells)                                                                              \
-      return coll ? launch_team_t<P, true, TW_FALLBACK, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)            \
-                  : launch_team_t<P, false, TW_FALLBACK, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite);          \
-    return coll ? launch_block_t<P, true, LPC>(mf, coef, src, dst, overwrite) : launch_block_t<P, false, LPC>(mf, coef, src, dst, overwrite)
-    BLOCK_CASE(1, 50, 4, 4, true);
-    BLOCK_CASE(2, 50, 9, 4, true);
-    BLOCK_CASE(3, 50, 16, 4, true);
-    BLOCK_CASE(4, 50, 25, 4, true);
-    BLOCK_CASE(4, 51, 32, 4, true);
-    case 454: case 455:
-      if (c0 == 0 && c1 == mf->n_cells) {
-        mf->block_shared_atomic = true;
-        const int st_ = variant == 454 - 400 ? (coll ? launch_block_t<4, true, 32>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32>(mf, coef, src, dst, overwrite))
-                                             : (coll ? launch_block_t<4, true, 25>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25>(mf, coef, src, dst, overwrite));
-        mf->block_shared_atomic = false;
-        return st_;
-      }
-      return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
-    case 448: // = 56 with the per-DoF CSR combine kernel instead of the run-length one (A/B)
-    case 449: // = 56 with run-length write-out but without packed indices (A/B)
-    case 456: if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
-        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
-        mf->combine_csr = variant == 48;
-        bp5_mf::DevPlan *dp_ = nullptr;
-        BP5_TRY(get_plan_raw(mf, -8, &dp_));
-        if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream
-          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
-                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);
-        if (dp_->max_runs <= (uint32_t)BLOCK_MAX_RUNS) // write-out without list loads
-          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite);
-        return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
-      }
-      return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
-    case 459: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
-      return fail(BP5_ERR_INVALID, "variant 59 needs the whole cell range");
-    case 457: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 8192>(mf, coef, src, dst, overwrite);
-      return fail(BP5_ERR_INVALID, "variant 57 needs the whole cell range");
-    case 458: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite);
-      return fail(BP5_ERR_INVALID, "variant 58 needs the whole cell range");
-    case 499: return launch_block_t<4, false, 32, 4096 + 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, true);   // stamps of the default shape (sequential tiles, 3 WG/CU, run write-out, packed indices)
-    case 452: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
-      return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range");
-    case 453: if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
-      return fail(BP5_ERR_INVALID, "variant 53 needs the whole cell range");
-    case 487: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 65536>(mf, coef, src, dst, true);  // variant 56 with plain (not non-temporal) stores
-    case 491: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 1>(mf, coef, src, dst, true);  // variant 56 without write-out (and combine)
-    case 493: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 2>(mf, coef, src, dst, true);  // ... without metric loads
-    case 495: return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 4>(mf, coef, src, dst, true);  // ... without gather
-    case 497: return launch_block_t<4, false, 32, 4096>(mf, coef, src, dst, true);          // stamps, double-buffered
-    case 498: return launch_block_t<4, false, 32, 4096 + 2048>(mf, coef, src, dst, true);   // stamps, single-buffered
-    case 492: return launch_block_t<4, false, 32, 2049>(mf, coef, src, dst, true);
-    case 496: return launch_block_t<4, false, 32, 2053>(mf, coef, src, dst, true);
-    BLOCK_CASE(5, 50, 36, 4, true);
-    BLOCK_CASE(6, 50, 49, 4, false);
-    BLOCK_CASE(7, 50, 64, 4, false);
-    BLOCK_CASE(8, 50, 81, 4, false);
-#define BABL_CASE(M) case 400 + 60 + (M): return launch_block_t<4, false, 25, M>(mf, coef, src, dst, true)
-    BABL_CASE(16); BABL_CASE(1); BABL_CASE(2); BABL_CASE(3); BABL_CASE(4); BABL_CASE(5); BABL_CASE(7); BABL_CASE(8); BABL_CASE(9); BABL_CASE(15);
-    // timing-only ablations of the team kernel (SET mode): 40 + mask (1: no scatter stage, 4: no gather stage)
-#define TABL_CASE(M)                                                                                               \
-  case 400 + 40 + (M): {                                                                                           \
-    TeamPlan tp; bp5_mf::DevPlan *dp = nullptr;                                                                    \
-    BP5_TRY(get_plan(mf, 10, tp, &dp));                                                                            \
-    ApplyArgs a; a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst; a.plane_stride = (uint64_t)mf->n_cells * mf->n3; \
-    a.cell_begin = c0; a.cell_end = c1; a.n_teams = (c1 + 9) / 10 - c0 / 10; a.teams_per_xcd = (a.n_teams + 7) / 8;  \
-    ShapeArg<5> sh; memcpy(sh.N, mf->tab.N, sizeof(sh.N)); memcpy(sh.D, mf->tab.D, sizeof(sh.D));                  \
-    hipLaunchKernelGGL((apply_team_kernel<4, false, 4, 25, true, SC_OWNER_SET, M>), dim3(a.teams_per_xcd * 8), dim3(256), \
-                       (10 * LdsLayout<5, 25>::CS * sizeof(double)), mf->stream, a, tp, sh);                          \
-    KERNEL_CHECK(); return BP5_OK; }
-    TABL_CASE(0); TABL_CASE(1); TABL_CASE(4); TABL_CASE(5);
-    // team-assembled kernel (LDS-staged gather + scatter), variants 10+
-    TEAM_CASE(1, 10, 4, 4, true);
-    TEAM_CASE(2, 10, 4, 9, true);
-    TEAM_CASE(3, 10, 4, 16, true);
-    TEAM_CASE(4, 10, 4, 25, true);
-    TEAM_CASE(4, 11, 8, 25, true);
-    TEAM_CASE(4, 12, 4, 25, false);
-    TEAM_CASE(4, 13, 2, 25, true);
-    case 414: return coll ? launch_team_t<4, true, 4, 25, true, 32>(mf, coef, src, dst, c0, c1, overwrite)
-                          : launch_team_t<4, false, 4, 25, true, 32>(mf, coef, src, dst, c0, c1, overwrite);
-    TEAM_CASE(5, 10, 4, 36, true);
-    TEAM_CASE(6, 10, 4, 49, false);
-    TEAM_CASE(7, 10, 4, 64, false);
-    TEAM_CASE(8, 10, 4, 81, false);
-  }
-  return fail(BP5_ERR_INVALID, "unknown (degree, apply variant)");
+  return fail(BP5_ERR_INVALID, "unsupported degree");
 }
 static int launch_apply(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite = false)
 {
@@ -1170,8 +665,13 @@ extern "C" int bp5_l2_norm_solution(bp5_mf *mf, const double *u, double *result)
 {
   if (!mf || !u || !result) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(mf->device));
+  // the cell integrals read ghost DoFs through local_to_global: refresh them first, as the reference does on its ghosted copy
+  // (ghost_solution_host, bp5/step-64.cu:602-616; deal.II's update_ghost_values() is const as well), and leave them zeroed
+  const bool ghosts = mf->comm && !mf->neighbors.empty();
+  if (ghosts) BP5_TRY(bp5_halo_gather(mf, const_cast<double *>(u)));
   HIP_TRY(hipMemsetAsync(mf->d_scalar, 0, sizeof(double), mf->stream));
   BP5_TRY(l2_dispatch(mf, u, mf->d_scalar));
+  if (ghosts) BP5_TRY(bp5_halo_zero_ghosts(mf, const_cast<double *>(u)));
   if (mf->comm) BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_scalar, 1));
   double s = 0.0;
   HIP_TRY(hipMemcpyAsync(&s, mf->d_scalar, sizeof(double), hipMemcpyDeviceToHost, mf->stream));
@@ -1417,7 +917,7 @@ static int ensure_ws(bp5_mf *mf)
   const size_t nb = (std::max<size_t>(mf->n_local(), 2) * sizeof(double) + 4095) / 4096 * 4096;
   char *base = nullptr;
   HIP_TRY(hipMalloc((void **)&base, 3 * nb + 2 * stagger + 4096));
-  HIP_TRY(hipMemset(base, 0, 3 * nb + 2 * stagger + 4096));
+  HIP_TRY(hipMemsetAsync(base, 0, 3 * nb + 2 * stagger + 4096, mf->stream)); // ordered with the solver kernels that follow on this stream
   mf->ws_base = base;
   mf->ws_g = (double *)base;
   mf->ws_d = (double *)(base + nb + stagger);
@@ -1431,9 +931,11 @@ struct ApplyProfile {
   bp5_mf *mf;
   bool on;
   int used = 0;
+  static constexpr int MAX_PROFILED = 512; // applications bracketed per solve; later ones run unbracketed (bounded pool)
   int mark(int k)
   {
     if (!on) return BP5_OK;
+    if (used >= 4 * MAX_PROFILED) { on = false; return BP5_OK; }
     while ((size_t)used + 4 > mf->ev_pool.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
     HIP_TRY(hipEventRecord(mf->ev_pool[used + k], mf->stream));
     return BP5_OK;
@@ -1487,9 +989,11 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
   hipStream_t s = mf->stream;
   double *g = mf->ws_g, *d = mf->ws_d, *h = mf->ws_h;
   ApplyProfile prof{mf, prm->profile != 0};
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
+  if (prof.on) { // create the bracketing events before the timed region starts
+    const size_t want = 4 * (size_t)std::min(prm->max_iter, ApplyProfile::MAX_PROFILED);
+    while (mf->ev_pool.size() < want) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
+  }
+  const hipEvent_t ev0 = mf->ev_solve[0], ev1 = mf->ev_solve[1];
   // scalars: tolerance + iteration cap
   mf->h_sc[SC_TOL] = prm->abs_tol;
   HIP_TRY(hipMemcpyAsync(mf->d_sc + SC_TOL, mf->h_sc + SC_TOL, sizeof(double), hipMemcpyHostToDevice, s));
@@ -1565,8 +1069,6 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
   BP5_TRY(poll_state(mf));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  hipEventDestroy(ev0);
-  hipEventDestroy(ev1);
   res->iterations = mf->h_st[ST_ITER];
   res->residual = mf->h_sc[SC_RES];
   res->initial_residual = mf->h_sc[SC_RES0];

@@ -1,0 +1,593 @@
+// Shared by the device translation units of libbp5: the handle, the launch templates of the fused operator kernels and the
+// per-degree variant dispatch.  bp5_device.hip holds the C ABI; bp5_apply_pN.hip instantiate apply_degree_impl<N> (one
+// translation unit per degree so that `make -j` compiles them side by side).
+#pragma once
+#include "bp5_internal.hpp"
+#include "bp5_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+using namespace bp5;
+
+#define HIP_TRY(expr)                                                                                              \
+  do {                                                                                                             \
+    hipError_t e_ = (expr);                                                                                        \
+    if (e_ != hipSuccess)                                                                                          \
+      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? BP5_ERR_NO_DEVICE : BP5_ERR_HIP,         \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                              \
+  } while (0)
+#define NCCL_TRY(expr)                                                                                             \
+  do {                                                                                                             \
+    ncclResult_t r_ = (expr);                                                                                      \
+    if (r_ != ncclSuccess) return fail(BP5_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));         \
+  } while (0)
+#define BP5_TRY(expr)                                                                                              \
+  do {                                                                                                             \
+    int s_ = (expr);                                                                                               \
+    if (s_ != BP5_OK) return s_;                                                                                   \
+  } while (0)
+#define KERNEL_CHECK() HIP_TRY(hipGetLastError())
+
+struct bp5_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 1;
+};
+struct bp5_event {
+  hipEvent_t ev = nullptr;
+};
+
+struct bp5_mf {
+  int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
+  uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
+  int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
+  uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
+  bool combine_csr = false; // A/B: per-DoF CSR combine kernel instead of the run-length one
+  int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
+  int auto_team = -1;  // -1 not decided; 1: the x-row team plan could be built (p = 1, 3 default)
+  int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
+  double *d_scalar_plane = nullptr, *d_gcell = nullptr;
+  bool force_atomic_scatter = false, block_shared_atomic = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Tables tab, tab_gauss;
+  // device arrays
+  uint32_t *d_l2g = nullptr, *d_constrained = nullptr, *d_send_idx = nullptr;
+  double *d_coords = nullptr, *d_tab = nullptr, *d_tab_gauss = nullptr;
+  // Data mirror (lazy)
+  uint32_t *d_l2g_padded = nullptr, *d_constraint_mask = nullptr;
+  double *d_inv_jac = nullptr, *d_JxW = nullptr, *d_qpoints = nullptr;
+  uint32_t pad = 0;
+  // halo plan
+  std::vector<int> neighbors;
+  std::vector<uint32_t> send_off, recv_off;
+  double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+  bp5_comm *comm = nullptr;
+  // solver workspace
+  double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
+  int *d_st = nullptr;
+  double *ws_g = nullptr, *ws_d = nullptr, *ws_h = nullptr, *d_evec = nullptr;
+  char *ws_base = nullptr;
+  unsigned long long *d_stamps = nullptr;
+  double *h_sc = nullptr; // pinned
+  int *h_st = nullptr;    // pinned
+  std::vector<hipEvent_t> ev_pool;
+  hipEvent_t ev_solve[2] = {nullptr, nullptr}; // start / stop of a solve (owned by the handle: no leak on error paths)
+  hipEvent_t prof_mark = nullptr; // profiling: recorded once before the combine pass (= end of the dominant kernel)
+  // team plans of the team-assembled kernel, keyed by cells per team
+  std::vector<uint32_t> h_l2g;
+  struct DevPlan {
+    uint32_t *off = nullptr, *dofs = nullptr, *sh_dof = nullptr, *sh_off = nullptr, *sh_slot = nullptr;
+    uint16_t *pos = nullptr;
+    uint8_t *cell_round = nullptr, *team_rounds = nullptr;
+    double *partial = nullptr;
+    uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
+    uint16_t *packed = nullptr;
+    std::vector<double> h_cost;                       // [n_groups+1] prefix sum of the estimated cost of the blocks (pass units)
+    uint32_t *wg_block = nullptr;                     // cached ranges for (wg_n, wg_b0, wg_b1)
+    uint32_t wg_n = 0, wg_b0 = 0, wg_b1 = 0;
+    uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
+    uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
+    bool covers_all = false;
+  };
+  std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
+  struct DevMarch { uint32_t *team_off = nullptr, *entries = nullptr; uint32_t n_teams = 0; };
+  std::map<int, DevMarch> march_plans; // keyed by cells per team
+  std::map<int, DevPlan> plans;
+  size_t n_local() const { return (size_t)n_owned + n_ghost; }
+};
+
+template <typename T>
+inline int upload(T **dptr, const T *host, size_t count)
+{
+  HIP_TRY(hipMalloc((void **)dptr, std::max<size_t>(count, 1) * sizeof(T)));
+  if (count) HIP_TRY(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+  return BP5_OK;
+}
+
+// defined in bp5_device.hip
+// key > 0: uniform teams of `key` cells (team kernel); key < 0: cell blocks walked in passes of
+// -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
+int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block = 64);
+int get_plan(bp5_mf *mf, int cpt, bp5::TeamPlan &tp, bp5_mf::DevPlan **dpo);
+int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set);
+// [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
+bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1);
+
+// ------------------------------------------------------------------------------------ operator launches
+template <int P, bool COLL, int TW, int LPC, int TPB, bool PF, int ABL = 0>
+inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 64 * TW / LPC;
+  using L = LdsLayout<n, LPC>;
+  ApplyArgs a{};
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = c0; a.cell_end = c1;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  a.n_teams = (c1 - c0 + CPT - 1) / CPT;
+  const uint32_t nblk = (a.n_teams + TPB - 1) / TPB;
+  a.teams_per_xcd = (nblk + 7) / 8;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const size_t lds = (size_t)TPB * CPT * L::CS * sizeof(double);
+  hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF, ABL>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
+                     sh);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+
+// block-assembled kernel; falls back to the team kernel path when the range is partial
+template <int P, bool COLL, int LPC, int ABL = 0>
+inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, double *dst, bool overwrite)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 256 / LPC;
+  using L = LdsLayout<n, LPC>;
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan_raw(mf, -CPT, &dp));
+  const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
+  const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
+  if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
+  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 64 runs per block: packed indices unavailable");
+  if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
+  BlockPlan bp{}; // value-initialised: a field this launcher forgets is null, not garbage
+  bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;
+  bp.packed = dp->packed;
+  bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
+  bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
+  // a block-aligned cell range: only these blocks run, accumulate mode; DoFs shared with other blocks go to dst by
+  // atomics (the partial slab + combine pass needs every block of the plan in the launch)
+  const bool sub_range = mf->blk_b1 > mf->blk_b0 && (mf->blk_b0 != 0 || mf->blk_b1 != dp->n_groups);
+  bp.blk_begin = sub_range ? mf->blk_b0 : 0;
+  if (sub_range) bp.n_blocks = mf->blk_b1 - mf->blk_b0;
+  if (sub_range && overwrite) return fail(BP5_ERR_INVALID, "a cell range cannot overwrite dst");
+  // persistent grid: two workgroups per CU (LDS budget), a multiple of 8 for the XCD mapping
+  if (!mf->n_cus) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
+    mf->n_cus = prop.multiProcessorCount;
+  }
+  const int wg_per_cu = ((ABL & 2048) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1;
+  uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
+  if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
+  n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
+  bp.n_wg = n_wg;
+  { // block ranges of the persistent workgroups: equal shares of the estimated COST (thin or partial bricks are cheaper per
+    // block but dearer per cell than full ones), cached
+    const uint32_t B0 = bp.blk_begin, B1 = bp.blk_begin + bp.n_blocks;
+    if (!dp->wg_block || dp->wg_n != n_wg || dp->wg_b0 != B0 || dp->wg_b1 != B1) {
+      std::vector<uint32_t> wb(n_wg + 1);
+      const std::vector<double> &pc = dp->h_cost;
+      const double c0 = pc[B0], total = pc[B1] - c0;
+      for (uint32_t w = 0; w <= n_wg; ++w)
+        wb[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + B1 + 1, c0 + total * w / n_wg - 1e-9) - pc.begin());
+      wb[0] = B0; wb[n_wg] = B1;
+      if (dp->wg_block) { HIP_TRY(hipStreamSynchronize(mf->stream)); HIP_TRY(hipFree(dp->wg_block)); dp->wg_block = nullptr; }
+      BP5_TRY(upload(&dp->wg_block, wb.data(), wb.size()));
+      dp->wg_n = n_wg; dp->wg_b0 = B0; dp->wg_b1 = B1;
+    }
+    bp.wg_block = dp->wg_block;
+  }
+  bp.stamps = nullptr;
+  if (ABL & 4096) {
+    if (!mf->d_stamps) HIP_TRY(hipMalloc((void **)&mf->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(mf->d_stamps, 0, 4096 * 16 * sizeof(unsigned long long), mf->stream));
+    bp.stamps = mf->d_stamps;
+  }
+  ApplyArgs a{};
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const bool set = overwrite && dp->covers_all;
+  if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  const dim3 grid(n_wg), block(256);
+  if (mf->block_shared_atomic || sub_range) {
+    // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
+    if (set && dp->n_shared) {
+      hipLaunchKernelGGL(zero_indexed_kernel, dim3((dp->n_shared + 255) / 256), dim3(256), 0, mf->stream, dp->sh_dof, dp->n_shared, dst);
+      KERNEL_CHECK();
+    }
+    if (set) {
+      auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET_ATOMIC, ABL>;
+      HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+    } else {
+      auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD_ATOMIC, ABL>;
+      HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+    }
+    KERNEL_CHECK();
+    return BP5_OK;
+  }
+  if (set) {
+    auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET, ABL>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+  } else {
+    auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD, ABL>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
+  }
+  KERNEL_CHECK();
+  if (ABL & 4096) { // diagnostic build: print the per-phase cycle shares (never quote its run time)
+    HIP_TRY(hipStreamSynchronize(mf->stream));
+    std::vector<unsigned long long> hs((size_t)n_wg * 16);
+    HIP_TRY(hipMemcpy(hs.data(), mf->d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double tot[9] = {0};
+    for (uint32_t w = 0; w < n_wg; ++w) for (int k = 0; k < 9; ++k) tot[k] += (double)hs[(size_t)w * 16 + k];
+    double all = 0; for (int k = 0; k < 7; ++k) all += tot[k];
+    static const char *nm[7] = {"issue loads", "evaluate (+wait u)", "wait idx + issue gather", "q-op (+wait metric)", "integrate", "accumulate", "block boundary"};
+    fprintf(stderr, "[bp5 stamps] passes/wg %.1f, cycles/pass %.0f\n", tot[8] / n_wg, all / tot[8]);
+    for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
+  }
+  if (ABL & 1023) return BP5_OK; // (1024 and above are real modes) timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
+  return launch_combine(mf, dp, dst, set);
+}
+
+// overwrite == true: dst need not be zeroed by the caller, the launch defines every entry
+template <int P, bool COLL, int TW, int LPC, bool PF, int OPT = 0>
+inline int launch_team_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 64 * TW / LPC;
+  using L = LdsLayout<n, LPC>;
+  TeamPlan tp{};
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan(mf, CPT, tp, &dp));
+  ApplyArgs a{};
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = c0; a.cell_end = c1;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  a.n_teams = (c1 + CPT - 1) / CPT - c0 / CPT;
+  a.teams_per_xcd = (a.n_teams + 7) / 8;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const size_t lds = (size_t)CPT * L::CS * sizeof(double);
+  const dim3 grid(a.teams_per_xcd * 8), block(64 * TW);
+  const bool whole = (c0 == 0 && c1 == mf->n_cells);
+  if (!whole || mf->force_atomic_scatter) {
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_ATOMIC, OPT>), grid, block, lds, mf->stream, a, tp, sh);
+  } else {
+    const bool set = overwrite && dp->covers_all;
+    if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    if (set) hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_SET, OPT>), grid, block, lds, mf->stream, a, tp, sh);
+    else hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_OWNER_ADD, OPT>), grid, block, lds, mf->stream, a, tp, sh);
+    KERNEL_CHECK();
+    return launch_combine(mf, dp, dst, set);
+  }
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+#define TEAM_CASE(P, V, TW, LPC, PF)                                                                               \
+  BP5_CASE(P, V)                                                                                                   \
+    return coll ? launch_team_t<P, true, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)                       \
+                : launch_team_t<P, false, TW, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)
+
+// z-marching kernel (whole cell range only; partial ranges take the plain pencil kernel)
+template <int P, bool COLL, int TW, int LPC, bool PF, int ABL = 0>
+inline int launch_march_t(bp5_mf *mf, const double *coef, const double *src, double *dst)
+{
+  constexpr int n = P + 1;
+  constexpr int CPT = 64 * TW / LPC;
+  using L = LdsLayout<n, LPC>;
+  auto it = mf->march_plans.find(CPT);
+  if (it == mf->march_plans.end()) {
+    MarchPlanHost h;
+    BP5_TRY(build_march_plan(mf->h_l2g.data(), mf->n_cells, n, CPT, mf->march_max_steps, h));
+    bp5_mf::DevMarch dm;
+    BP5_TRY(upload(&dm.team_off, h.team_off.data(), h.team_off.size()));
+    BP5_TRY(upload(&dm.entries, h.entries.data(), h.entries.size()));
+    dm.n_teams = (uint32_t)h.team_off.size() - 1;
+    it = mf->march_plans.emplace(CPT, dm).first;
+  }
+  MarchPlan mp{};
+  mp.team_off = it->second.team_off; mp.entries = it->second.entries; mp.n_teams = it->second.n_teams;
+  mp.teams_per_xcd = (mp.n_teams + 7) / 8;
+  ApplyArgs a{};
+  a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
+  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = mp.n_teams; a.teams_per_xcd = mp.teams_per_xcd;
+  a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  ShapeArg<n> sh;
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  const size_t lds = (size_t)CPT * L::CS * sizeof(double);
+  hipLaunchKernelGGL((apply_march_kernel<P, COLL, TW, LPC, PF, ABL>), dim3(mp.teams_per_xcd * 8), dim3(64 * TW), lds, mf->stream, a, mp, sh);
+  KERNEL_CHECK();
+  return BP5_OK;
+}
+
+// variant table: (degree, variant) -> (TW, LPC, TPB, PF); variant 0 = default for the degree
+#define APPLY_CASE(P, V, TW, LPC, TPB, PF)                                                                         \
+  BP5_CASE(P, V) {                                                                                                 \
+    if (overwrite && hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream) != hipSuccess)             \
+      return fail(BP5_ERR_HIP, "hipMemsetAsync");                                                                  \
+    return coll ? launch_apply_t<P, true, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1)                            \
+                : launch_apply_t<P, false, TW, LPC, TPB, PF>(mf, coef, src, dst, c0, c1);                          \
+  }
+
+// overwrite: the launch must leave dst = A src (no prior zeroing by the caller); otherwise dst += A src
+template <int P>
+inline int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0, uint32_t c1)
+{ // TW = 4 teams when n^2 lanes per cell pack well into 256 threads, as for the 6-plane default
+  constexpr int n2 = (P + 1) * (P + 1);
+  constexpr int LPC = n2;
+  constexpr bool PF = true;
+  return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<P, true, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1)
+                                        : launch_apply_t<P, false, 4, LPC, 1, PF, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1);
+}
+
+// (degree, variant) -> kernel.  One instantiation per degree: only the cases of DEG are compiled into it.
+#define BP5_CASE(P, V) if constexpr (DEG == (P)) if (variant == (V))
+template <int DEG>
+int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
+{
+  if (mf->geometry_mode == BP5_GEOM_AFFINE && c1 > c0) {
+    const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
+    const bool whole = c0 == 0 && c1 == mf->n_cells;
+    if constexpr (DEG == 4) {
+    if (mf->apply_variant % 100 == 10) {
+      mf->force_atomic_scatter = mf->apply_variant >= 100;
+      return coll_ ? launch_team_t<4, true, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite)
+                   : launch_team_t<4, false, 4, 25, true, 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1, overwrite);
+    }
+    if (mf->apply_variant == 56) { // the default block-kernel shape on the scalar plane + per-cell K K^T
+      if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
+      struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+      return coll_ ? launch_block_t<4, true, 32, 1024 + 2048 + 8192 + 16384 + 262144>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                   : launch_block_t<4, false, 32, 1024 + 2048 + 8192 + 16384 + 262144>(mf, mf->d_scalar_plane, src, dst, overwrite);
+    }
+    if (whole && (mf->apply_variant == 54 || mf->apply_variant == 55)) {
+      mf->block_shared_atomic = true;
+      const int st_ = mf->apply_variant == 54 ? (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                                       : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
+                                              : (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                                       : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
+      mf->block_shared_atomic = false;
+      return st_;
+    }
+    if (whole && (mf->apply_variant == 50 || mf->apply_variant == 51))
+      return mf->apply_variant == 50 ? (coll_ ? launch_block_t<4, true, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                              : launch_block_t<4, false, 25, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite))
+                                     : (coll_ ? launch_block_t<4, true, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite)
+                                              : launch_block_t<4, false, 32, 1024>(mf, mf->d_scalar_plane, src, dst, overwrite));
+#ifdef BP5_TIMING_BUILDS
+    if (mf->apply_variant == 85) // timing only: affine, no scatter atomics -> compute/latency floor of the pencil kernel
+      return launch_apply_t<4, false, 4, 25, 1, true, 1025>(mf, mf->d_scalar_plane, src, dst, c0, c1);
+#endif
+    }
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    return launch_affine<DEG>(mf, src, dst, c0, c1);
+  }
+  if (c1 <= c0) {
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    return BP5_OK;
+  }
+  const bool coll = mf->quadrature == BP5_QUAD_GLL;
+  // variants >= 100: the team kernel of (variant - 100) with the global-atomic scatter (A/B tests)
+  mf->force_atomic_scatter = mf->apply_variant >= 100;
+  int variant = mf->apply_variant % 100;
+  {
+    APPLY_CASE(1, 0, 1, 4, 4, true);
+    APPLY_CASE(1, 1, 1, 4, 4, true);
+    APPLY_CASE(2, 0, 1, 9, 4, true);
+    APPLY_CASE(3, 0, 1, 16, 4, true);
+    APPLY_CASE(3, 1, 1, 16, 4, true);
+    APPLY_CASE(4, 0, 4, 25, 1, true);
+    APPLY_CASE(4, 6, 1, 25, 4, true);
+    APPLY_CASE(4, 1, 1, 32, 4, true);
+    APPLY_CASE(4, 2, 2, 25, 1, true);
+    APPLY_CASE(4, 3, 4, 25, 1, true);
+    APPLY_CASE(4, 4, 1, 25, 1, true);
+    APPLY_CASE(4, 5, 1, 25, 4, false);
+    APPLY_CASE(5, 0, 4, 36, 1, true);
+    APPLY_CASE(5, 1, 1, 36, 4, true);
+    APPLY_CASE(5, 2, 4, 36, 1, false);
+    APPLY_CASE(5, 3, 2, 36, 1, true);
+    APPLY_CASE(6, 0, 4, 49, 1, true);   // defaults for p >= 6 from the high-degree sweep: prefetch all planes
+    APPLY_CASE(6, 5, 4, 49, 1, false);
+    APPLY_CASE(6, 1, 1, 49, 4, false);
+    APPLY_CASE(6, 2, 4, 49, 1, true);
+    APPLY_CASE(6, 3, 1, 49, 1, true);
+    APPLY_CASE(6, 4, 2, 49, 1, false);
+    APPLY_CASE(7, 0, 4, 64, 1, true);
+    APPLY_CASE(7, 5, 1, 64, 4, false);
+    APPLY_CASE(7, 1, 4, 64, 1, false);
+    APPLY_CASE(7, 2, 4, 64, 1, true);
+    APPLY_CASE(7, 3, 1, 64, 1, true);
+    APPLY_CASE(8, 0, 4, 81, 1, true);
+    APPLY_CASE(8, 5, 4, 81, 1, false);
+    APPLY_CASE(8, 1, 2, 81, 1, false);
+    APPLY_CASE(8, 2, 4, 81, 1, true);
+    APPLY_CASE(8, 3, 2, 81, 1, true);
+#ifdef BP5_TIMING_BUILDS
+    // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
+#define ABL_CASE(M) BP5_CASE(4, 20 + (M)) return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
+    BP5_CASE(4, 7) return coll ? launch_apply_t<4, true, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 8) return coll ? launch_apply_t<4, true, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 9) return coll ? launch_apply_t<4, true, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 82) return launch_apply_t<4, false, 4, 25, 1, true, 257>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 83) return launch_apply_t<4, false, 4, 25, 1, true, 4096>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 84) return launch_apply_t<4, false, 4, 25, 1, true, 8192>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 80) return launch_apply_t<4, false, 4, 25, 1, true, 64>(mf, coef, src, dst, c0, c1);
+    BP5_CASE(4, 81) { // E-vector stores need a big scratch target
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 128>(mf, coef, src, mf->d_evec, c0, c1); }
+    BP5_CASE(4, 90) {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, ((size_t)mf->n_cells * mf->n3 + 4096 * 5) * sizeof(double) * 2));
+      return launch_apply_t<4, false, 4, 25, 1, true, 262144>(mf, coef, src, mf->d_evec, c0, c1); }
+    BP5_CASE(4, 88) {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 128 + 65536>(mf, coef, src, mf->d_evec, c0, c1); }
+    BP5_CASE(4, 89) {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 1 + 131072>(mf, coef, src, mf->d_evec, c0, c1); }
+    BP5_CASE(4, 86) {
+      if (!mf->d_evec) HIP_TRY(hipMalloc((void **)&mf->d_evec, (size_t)mf->n_cells * mf->n3 * sizeof(double)));
+      return launch_apply_t<4, false, 4, 25, 1, true, 128 + 16384>(mf, coef, src, mf->d_evec, c0, c1); }
+    ABL_CASE(1); ABL_CASE(2); ABL_CASE(3); ABL_CASE(4); ABL_CASE(5); ABL_CASE(7); ABL_CASE(8); ABL_CASE(9); ABL_CASE(15); ABL_CASE(14); ABL_CASE(13); ABL_CASE(11);
+#endif
+    // z-marching kernel, variants 70+ (atomic scatter: dst must be zero-filled like for the pencil kernel)
+#define MARCH_CASE(P, V, TW, LPC, PF)                                                                              \
+  BP5_CASE(P, V) {                                                                                                 \
+    if (overwrite && hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream) != hipSuccess)             \
+      return fail(BP5_ERR_HIP, "hipMemsetAsync");                                                                  \
+    if (c0 != 0 || c1 != mf->n_cells)                                                                              \
+      return coll ? launch_apply_t<P, true, TW, LPC, 1, PF>(mf, coef, src, dst, c0, c1)                            \
+                  : launch_apply_t<P, false, TW, LPC, 1, PF>(mf, coef, src, dst, c0, c1);                          \
+    return coll ? launch_march_t<P, true, TW, LPC, PF>(mf, coef, src, dst) : launch_march_t<P, false, TW, LPC, PF>(mf, coef, src, dst); \
+  }
+#ifdef BP5_TIMING_BUILDS
+    BP5_CASE(4, 73) return launch_march_t<4, false, 4, 25, true, 1>(mf, coef, src, dst); // timing only: march, no scatter
+#endif
+    MARCH_CASE(1, 70, 4, 4, true);
+    MARCH_CASE(2, 70, 4, 9, true);
+    MARCH_CASE(3, 70, 4, 16, true);
+    MARCH_CASE(4, 70, 4, 25, true);
+    MARCH_CASE(4, 71, 2, 25, true);
+    MARCH_CASE(4, 72, 1, 25, true);
+    MARCH_CASE(5, 70, 4, 36, true);
+    MARCH_CASE(6, 70, 4, 49, true);
+    MARCH_CASE(7, 70, 4, 64, true);
+    MARCH_CASE(8, 70, 4, 81, true);
+    // block-assembled kernel (compact cell blocks, LDS accumulator, no atomics), variants 50+;
+    // a partial cell range cannot use the owner scatter and takes the atomic team kernel instead
+#define BLOCK_CASE(P, V, LPC, TW_FALLBACK, PF)                                                                     \
+  BP5_CASE(P, V) {                                                                                                 \
+    if (c0 != 0 || c1 != mf->n_cells)                                                                              \
+      return coll ? launch_team_t<P, true, TW_FALLBACK, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite)            \
+                  : launch_team_t<P, false, TW_FALLBACK, LPC, PF>(mf, coef, src, dst, c0, c1, overwrite);          \
+    return coll ? launch_block_t<P, true, LPC>(mf, coef, src, dst, overwrite) : launch_block_t<P, false, LPC>(mf, coef, src, dst, overwrite); \
+  }
+    BLOCK_CASE(1, 50, 4, 4, true);
+    BLOCK_CASE(2, 50, 9, 4, true);
+    BLOCK_CASE(3, 50, 16, 4, true);
+    BLOCK_CASE(4, 50, 25, 4, true);
+    BLOCK_CASE(4, 51, 32, 4, true);
+    if constexpr (DEG == 4) if (variant == 54 || variant == 55) {
+      if (c0 == 0 && c1 == mf->n_cells) {
+        mf->block_shared_atomic = true;
+        const int st_ = variant == 54 ? (coll ? launch_block_t<4, true, 32>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32>(mf, coef, src, dst, overwrite))
+                                             : (coll ? launch_block_t<4, true, 25>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25>(mf, coef, src, dst, overwrite));
+        mf->block_shared_atomic = false;
+        return st_;
+      }
+      return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
+    }
+    // 48 = 56 with the per-DoF CSR combine kernel instead of the run-length one (A/B)
+    // 49 = 56 with run-length write-out but without packed indices (A/B)
+    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
+        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
+        mf->combine_csr = variant == 48;
+        bp5_mf::DevPlan *dp_ = nullptr;
+        BP5_TRY(get_plan_raw(mf, -8, &dp_));
+        if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);
+        if (dp_->max_runs <= (uint32_t)BLOCK_MAX_RUNS) // write-out without list loads
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 16384>(mf, coef, src, dst, overwrite);
+        return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
+      }
+      return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
+    }
+    BP5_CASE(4, 59) { if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 59 needs the whole cell range"); }
+    BP5_CASE(4, 57) { if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 8192>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 8192>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 57 needs the whole cell range"); }
+    BP5_CASE(4, 58) { if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048 + 8192 + 32768>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 58 needs the whole cell range"); }
+#ifdef BP5_TIMING_BUILDS
+    BP5_CASE(4, 99) return launch_block_t<4, false, 32, 4096 + 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, true);   // stamps of the default shape (sequential tiles, 3 WG/CU, run write-out, packed indices)
+#endif
+    BP5_CASE(4, 52) { if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 32, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 32, 2048>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 52 needs the whole cell range"); }
+    BP5_CASE(4, 53) { if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
+      return fail(BP5_ERR_INVALID, "variant 53 needs the whole cell range"); }
+#ifdef BP5_TIMING_BUILDS
+    BP5_CASE(4, 87) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 65536>(mf, coef, src, dst, true);  // variant 56 with plain (not non-temporal) stores
+    BP5_CASE(4, 91) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 1>(mf, coef, src, dst, true);  // variant 56 without write-out (and combine)
+    BP5_CASE(4, 93) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 2>(mf, coef, src, dst, true);  // ... without metric loads
+    BP5_CASE(4, 95) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 4>(mf, coef, src, dst, true);  // ... without gather
+    BP5_CASE(4, 97) return launch_block_t<4, false, 32, 4096>(mf, coef, src, dst, true);          // stamps, double-buffered
+    BP5_CASE(4, 98) return launch_block_t<4, false, 32, 4096 + 2048>(mf, coef, src, dst, true);   // stamps, single-buffered
+    BP5_CASE(4, 92) return launch_block_t<4, false, 32, 2049>(mf, coef, src, dst, true);
+    BP5_CASE(4, 96) return launch_block_t<4, false, 32, 2053>(mf, coef, src, dst, true);
+#endif
+    BLOCK_CASE(5, 50, 36, 4, true);
+    BLOCK_CASE(6, 50, 49, 4, false);
+    BLOCK_CASE(7, 50, 64, 4, false);
+    BLOCK_CASE(8, 50, 81, 4, false);
+#ifdef BP5_TIMING_BUILDS
+#define BABL_CASE(M) BP5_CASE(4, 60 + (M)) return launch_block_t<4, false, 25, M>(mf, coef, src, dst, true)
+    BABL_CASE(16); BABL_CASE(1); BABL_CASE(2); BABL_CASE(3); BABL_CASE(4); BABL_CASE(5); BABL_CASE(7); BABL_CASE(8); BABL_CASE(9); BABL_CASE(15);
+    // timing-only ablations of the team kernel (SET mode): 40 + mask (1: no scatter stage, 4: no gather stage)
+#define TABL_CASE(M)                                                                                               \
+  BP5_CASE(4, 40 + (M)) {                                                                                         \
+    TeamPlan tp; bp5_mf::DevPlan *dp = nullptr;                                                                    \
+    BP5_TRY(get_plan(mf, 10, tp, &dp));                                                                            \
+    ApplyArgs a; a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst; a.plane_stride = (uint64_t)mf->n_cells * mf->n3; \
+    a.cell_begin = c0; a.cell_end = c1; a.n_teams = (c1 + 9) / 10 - c0 / 10; a.teams_per_xcd = (a.n_teams + 7) / 8;  \
+    ShapeArg<5> sh; memcpy(sh.N, mf->tab.N, sizeof(sh.N)); memcpy(sh.D, mf->tab.D, sizeof(sh.D));                  \
+    hipLaunchKernelGGL((apply_team_kernel<4, false, 4, 25, true, SC_OWNER_SET, M>), dim3(a.teams_per_xcd * 8), dim3(256), \
+                       (10 * LdsLayout<5, 25>::CS * sizeof(double)), mf->stream, a, tp, sh);                          \
+    KERNEL_CHECK(); return BP5_OK; }
+    TABL_CASE(0); TABL_CASE(1); TABL_CASE(4); TABL_CASE(5);
+#endif
+    // team-assembled kernel (LDS-staged gather + scatter), variants 10+
+    TEAM_CASE(1, 10, 4, 4, true);
+    TEAM_CASE(2, 10, 4, 9, true);
+    TEAM_CASE(3, 10, 4, 16, true);
+    TEAM_CASE(4, 10, 4, 25, true);
+    TEAM_CASE(4, 11, 8, 25, true);
+    TEAM_CASE(4, 12, 4, 25, false);
+    TEAM_CASE(4, 13, 2, 25, true);
+    BP5_CASE(4, 14) return coll ? launch_team_t<4, true, 4, 25, true, 32>(mf, coef, src, dst, c0, c1, overwrite)
+                          : launch_team_t<4, false, 4, 25, true, 32>(mf, coef, src, dst, c0, c1, overwrite);
+    TEAM_CASE(5, 10, 4, 36, true);
+    TEAM_CASE(6, 10, 4, 49, false);
+    TEAM_CASE(7, 10, 4, 64, false);
+    TEAM_CASE(8, 10, 4, 81, false);
+  }
+  return fail(BP5_ERR_INVALID, "unknown (degree, apply variant)");
+}
+
+#define BP5_EXTERN_DEGREE(N) extern template int apply_degree_impl<N>(bp5_mf *, const double *, const double *, double *, uint32_t, uint32_t, bool);
+BP5_EXTERN_DEGREE(1) BP5_EXTERN_DEGREE(2) BP5_EXTERN_DEGREE(3) BP5_EXTERN_DEGREE(4) BP5_EXTERN_DEGREE(5) BP5_EXTERN_DEGREE(6) BP5_EXTERN_DEGREE(7) BP5_EXTERN_DEGREE(8)

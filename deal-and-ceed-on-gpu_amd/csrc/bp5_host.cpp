@@ -141,6 +141,7 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
   std::vector<uint32_t> count(n_teams, 0);
   // pass 1: distinct count per team, positions
   std::vector<std::vector<uint32_t>> lists(n_teams);
+  int too_long = 0, too_many_rounds = 0;
 #pragma omp parallel
   {
     std::vector<uint32_t> tmp;
@@ -150,13 +151,18 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
       tmp.assign(l2g + c0 * n3, l2g + c1 * n3);
       std::sort(tmp.begin(), tmp.end());
       tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      if (tmp.size() > 65536) { // positions are 16 bits: refuse before they are truncated
+#pragma omp atomic write
+        too_long = 1;
+        continue;
+      }
       for (size_t s = c0 * n3; s < c1 * n3; ++s)
         out.pos[s] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), l2g[s]) - tmp.begin());
       lists[t] = tmp;
     }
   }
+  if (too_long) return fail(BP5_ERR_UNSUPPORTED, "cell group touches more than 65536 DoFs (16-bit positions)");
   for (size_t t = 0; t < n_teams; ++t) {
-    if (lists[t].size() > 65536) return fail(BP5_ERR_UNSUPPORTED, "cell group touches more than 65536 DoFs (16-bit positions)");
     out.off[t + 1] = out.off[t] + (uint32_t)lists[t].size();
   }
   out.dofs.resize(out.off[n_teams]);
@@ -193,7 +199,12 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
           uint64_t used = 0;
           for (int i = 0; i < n3; ++i) used |= pos_mask[out.pos[c * n3 + i]];
           uint8_t r = 0;
-          while (used & (1ull << r)) ++r;
+          while (r < 64 && (used & (1ull << r))) ++r;
+          if (r >= 64) { // more than 64 mutually conflicting cells in one group: the 64-bit round masks are exhausted
+#pragma omp atomic write
+            too_many_rounds = 1;
+            r = 63;
+          }
           out.cell_round[c] = r;
           nr = std::max<uint8_t>(nr, r + 1);
           for (int i = 0; i < n3; ++i) pos_mask[out.pos[c * n3 + i]] |= 1ull << r;
@@ -224,9 +235,14 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
         for (int q = 0; q < (int)fill.size(); ++q) if (fill[q] < cells_per_pass && (pick < 0 || fill[q] < fill[pick])) pick = q;
         if (pick < 0) { pick = (int)fill.size(); fill.push_back(0); passes.resize(passes.size() + cells_per_pass, 0xffffffffu); }
         // round = 1 + highest round among conflicting cells already in that pass (conservative: next round)
-        uint8_t r = 0;
-        for (int k = 0; k < fill[pick]; ++k) r = std::max<uint8_t>(r, out.cell_round[passes[(size_t)pick * cells_per_pass + k]] + 1);
-        out.cell_round[c] = r;
+        int r = 0;
+        for (int k = 0; k < fill[pick]; ++k) r = std::max<int>(r, out.cell_round[passes[(size_t)pick * cells_per_pass + k]] + 1);
+        if (r > 254) { // rounds are 8 bits: a wrapped round would put conflicting cells in the same round
+#pragma omp atomic write
+          too_many_rounds = 1;
+          r = 254;
+        }
+        out.cell_round[c] = (uint8_t)r;
         nr = std::max<uint8_t>(nr, r + 1);
         passes[(size_t)pick * cells_per_pass + fill[pick]++] = c;
       }
@@ -241,7 +257,11 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
               for (int k = 0; k < fill[qa]; ++k) ra = std::max<uint8_t>(ra, out.cell_round[passes[(size_t)qa * cells_per_pass + k]]);
               for (int k = 0; k < fill[qb]; ++k) {
                 const uint32_t cb = passes[(size_t)qb * cells_per_pass + k];
-                out.cell_round[cb] = (uint8_t)(out.cell_round[cb] + ra + 1);
+                if ((int)out.cell_round[cb] + ra + 1 > 254) {
+#pragma omp atomic write
+                  too_many_rounds = 1;
+                }
+                out.cell_round[cb] = (uint8_t)std::min<int>(254, out.cell_round[cb] + ra + 1);
                 nr = std::max<uint8_t>(nr, out.cell_round[cb] + 1);
                 passes[(size_t)qa * cells_per_pass + fill[qa]++] = cb;
               }
@@ -258,6 +278,7 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
         for (int k = fill[q]; k < cells_per_pass; ++k) passes[q * cells_per_pass + k] = passes[q * cells_per_pass] | 0x80000000u;
     }
   }
+  if (too_many_rounds) return fail(BP5_ERR_UNSUPPORTED, "cell groups need too many accumulation rounds (highly irregular cell order): use the atomic kernel");
   if (cells_per_pass > 0) {
     for (size_t t = 0; t < n_teams; ++t) out.pass_off[t + 1] = out.pass_off[t] + (uint32_t)(group_passes[t].size() / cells_per_pass);
     out.pass_cell.resize((size_t)out.pass_off[n_teams] * cells_per_pass);

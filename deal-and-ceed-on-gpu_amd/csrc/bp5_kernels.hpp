@@ -1946,7 +1946,7 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
     atomic_add_f64(diag + l2g[cell * n3 + q], acc);
   }
 }
-__global__ void reciprocal_kernel(double *v, size_t n)
+static __global__ void reciprocal_kernel(double *v, size_t n)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = 1.0 / v[i];
@@ -2035,29 +2035,29 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
   if (ADD) dst[g] += s; else dst[g] = s;
 }
 
-__global__ void __launch_bounds__(256) zero_indexed_kernel(const uint32_t *idx, uint32_t n, double *dst)
+static __global__ void __launch_bounds__(256) zero_indexed_kernel(const uint32_t *idx, uint32_t n, double *dst)
 {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) dst[idx[i]] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------ small vector kernels
-__global__ void copy_constrained_kernel(const uint32_t *cdofs, uint32_t n, const double *src, double *dst)
+static __global__ void copy_constrained_kernel(const uint32_t *cdofs, uint32_t n, const double *src, double *dst)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const uint32_t c = cdofs[i]; dst[c] = src[c]; }
 }
-__global__ void set_constrained_kernel(const uint32_t *cdofs, uint32_t n, double val, double *dst)
+static __global__ void set_constrained_kernel(const uint32_t *cdofs, uint32_t n, double val, double *dst)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[cdofs[i]] = val;
 }
-__global__ void pack_kernel(const uint32_t *idx, uint32_t n, const double *v, double *buf)
+static __global__ void pack_kernel(const uint32_t *idx, uint32_t n, const double *v, double *buf)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) buf[i] = v[idx[i]];
 }
-__global__ void unpack_add_kernel(const uint32_t *idx, uint32_t n, const double *buf, double *v)
+static __global__ void unpack_add_kernel(const uint32_t *idx, uint32_t n, const double *buf, double *v)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[idx[i]] += buf[i]; // indices of one neighbour are distinct
@@ -2132,7 +2132,7 @@ __global__ void __launch_bounds__(VB) finalize_kernel(const double *partials, in
   }
 }
 
-__global__ void __launch_bounds__(VB) dot_kernel(const double *x, const double *y, size_t n, double *partials)
+static __global__ void __launch_bounds__(VB) dot_kernel(const double *x, const double *y, size_t n, double *partials)
 {
   double acc[1] = {0.0};
   const size_t stride = (size_t)gridDim.x * VB * 2;
@@ -2147,7 +2147,7 @@ __global__ void __launch_bounds__(VB) dot_kernel(const double *x, const double *
 }
 
 // number of nonzero (or NaN) entries, as a double so that it travels through the same reduction / all-reduce
-__global__ void __launch_bounds__(VB) count_nonzero_kernel(const double *x, size_t n, double *partials)
+static __global__ void __launch_bounds__(VB) count_nonzero_kernel(const double *x, size_t n, double *partials)
 {
   double acc[1] = {0.0};
   const size_t stride = (size_t)gridDim.x * VB;
@@ -2163,7 +2163,7 @@ enum { ST_DONE = 0, ST_ITER, ST_PENDING, ST_MAXIT, ST_BREAKDOWN, ST_COUNT };
 
 // ---- plain CG (deal.II SolverCG, Appendix A.5)
 // init: g = -b ; d = b (= -D g with D = 1) ; x = 0 ; partial sums of g.g and g.Dg
-__global__ void __launch_bounds__(VB) cg_init_kernel(const double *b, const double *diag, double *x, double *g, double *d,
+static __global__ void __launch_bounds__(VB) cg_init_kernel(const double *b, const double *diag, double *x, double *g, double *d,
                                                     size_t n, double *partials)
 {
   double acc[2] = {0.0, 0.0};
@@ -2176,7 +2176,7 @@ __global__ void __launch_bounds__(VB) cg_init_kernel(const double *b, const doub
   block_reduce_store<2>(acc, partials);
 }
 // after init: res0 = sqrt(gg); gh = gDg; done if res0 <= tol
-__global__ void cg_init_control_kernel(double *sc, int *st)
+static __global__ void cg_init_control_kernel(double *sc, int *st)
 {
   sc[SC_RES0] = sc[SC_RES] = sqrt(sc[SC_GG]);
   sc[SC_GH] = sc[SC_GDG];
@@ -2184,7 +2184,7 @@ __global__ void cg_init_control_kernel(double *sc, int *st)
   st[ST_DONE] = (sc[SC_RES] <= sc[SC_TOL]) ? 1 : 0;
 }
 // x += alpha d ; g += alpha h ; partial sums g.g, g.Dg   with alpha = gh / dh
-__global__ void __launch_bounds__(VB) cg_update_kernel(double *x, double *g, const double *d, const double *h, const double *diag,
+static __global__ void __launch_bounds__(VB) cg_update_kernel(double *x, double *g, const double *d, const double *h, const double *diag,
                                                       size_t n, const double *sc, const int *st, double *partials)
 {
   if (st[ST_DONE]) return;
@@ -2211,7 +2211,7 @@ __global__ void __launch_bounds__(VB) cg_update_kernel(double *x, double *g, con
   block_reduce_store<2>(acc, partials);
 }
 // res = sqrt(gg); ++it; stop test; beta = gDg / gh ; gh = gDg
-__global__ void cg_control_kernel(double *sc, int *st)
+static __global__ void cg_control_kernel(double *sc, int *st)
 {
   if (st[ST_DONE]) return;
   const double dh = sc[SC_DH];
@@ -2225,7 +2225,7 @@ __global__ void cg_control_kernel(double *sc, int *st)
   sc[SC_GH] = sc[SC_GDG];
 }
 // d = beta d - D g
-__global__ void __launch_bounds__(VB) cg_direction_kernel(double *d, const double *g, const double *diag, size_t n, const double *sc,
+static __global__ void __launch_bounds__(VB) cg_direction_kernel(double *d, const double *g, const double *diag, size_t n, const double *sc,
                                                          const int *st)
 {
   if (st[ST_DONE]) return;
@@ -2301,7 +2301,7 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, co
   }
 }
 // update_b (solver.h:142-311): [p.v, v.v, r.v, r.r, r.Dv, v.Dv, r.Dr]
-__global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const double *r, const double *v, const double *diag, size_t n,
+static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const double *r, const double *v, const double *diag, size_t n,
                                                      const int *st, double *partials)
 {
   if (st[ST_DONE]) return;
@@ -2323,7 +2323,7 @@ __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const dou
   block_reduce_store<7>(acc, partials);
 }
 // scalars of one merged iteration (solver.h:496-506,533)
-__global__ void cgm_control_kernel(double *sc, int *st)
+static __global__ void cgm_control_kernel(double *sc, int *st)
 {
   if (st[ST_DONE]) { st[ST_PENDING] = 0; return; }
   const double *R = sc + SC_R0;
@@ -2340,7 +2340,7 @@ __global__ void cgm_control_kernel(double *sc, int *st)
   sc[SC_BETA] = alpha * (R[4] + alpha * R[5]) / R[6];
 }
 // merged init: r = -b, x = 0, partial r.r
-__global__ void __launch_bounds__(VB) cgm_init_kernel(const double *b, double *x, double *r, double *p, double *v, size_t n,
+static __global__ void __launch_bounds__(VB) cgm_init_kernel(const double *b, double *x, double *r, double *p, double *v, size_t n,
                                                      double *partials)
 {
   double acc[2] = {0.0, 0.0};
@@ -2353,7 +2353,7 @@ __global__ void __launch_bounds__(VB) cgm_init_kernel(const double *b, double *x
   acc[1] = acc[0];
   block_reduce_store<2>(acc, partials);
 }
-__global__ void cgm_init_control_kernel(double *sc, int *st)
+static __global__ void cgm_init_control_kernel(double *sc, int *st)
 {
   sc[SC_RES0] = sc[SC_RES] = sqrt(sc[SC_GG]);
   sc[SC_ALPHA] = sc[SC_BETA] = sc[SC_ALPHA_OLD] = sc[SC_BETA_OLD] = 0.0;

@@ -229,7 +229,9 @@ int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag, int inver
 
 /* b_i = int phi_i with Gauss(p+1), constrained rows 0 (assemble_rhs, bp5/step-64.cu:372-418) */
 int bp5_assemble_rhs(bp5_mf *mf, double *b);
-/* ||u_h||_L2 by Gauss(p+1) quadrature (output_results, bp5/step-64.cu:602-616); synchronous */
+/* ||u_h||_L2 by Gauss(p+1) quadrature (output_results, bp5/step-64.cu:602-616); synchronous.  With a communicator and
+ * neighbours the ghost range of u is refreshed from its owners first (the reference integrates a ghosted copy,
+ * ghost_solution_host) and zeroed again afterwards -- the owned entries are never written. */
 int bp5_l2_norm_solution(bp5_mf *mf, const double *u, double *result_host);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -196,3 +196,23 @@ def test_pure_c_consumer_of_the_abi():
     subprocess.check_call(["make", "-s", "-C", cdir])
     r = subprocess.run([os.path.join(cdir, "abi_smoke")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_launches_its_own_ranks_and_strong_scales_by_default():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (child torch.distributed.run, before any GPU
+    call) and, by default, splits ONE problem into N z-slabs (BASELINE config 3: strong scaling); `--scaling weak` gives
+    every rank a slab of the N = 1 size.  Host-only dry run: no GPU, no process group."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(bp5_pkg.ROOT, "bench.py")
+    for mode, n_global in (("strong", (4 * 8 + 1) ** 2 * (4 * 10 + 1)), ("weak", (4 * 8 + 1) ** 2 * (4 * 20 + 1))):
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--cells", "8", "8", "10", "--scaling", mode, "--dry-run"],
+                           capture_output=True, text=True, timeout=600, cwd=bp5_pkg.ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        parts = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")), key=lambda d: d["rank"])
+        assert [d["rank"] for d in parts] == [0, 1] and all(d["world"] == 2 and d["scaling"] == mode for d in parts)
+        assert all(d["n_global_dofs"] == n_global for d in parts)
+        assert sum(d["n_owned"] for d in parts) == n_global                  # every DoF owned exactly once
+        assert sum(d["n_cells"] for d in parts) == 8 * 8 * (10 if mode == "strong" else 20)
+        assert parts[0]["neighbors"] == [1] and parts[1]["neighbors"] == [0] and parts[1]["n_ghost"] == 33 * 33

@@ -12,14 +12,14 @@ import bp5_pkg
 pytestmark = pytest.mark.gpu
 BENCH = os.path.join(bp5_pkg.ROOT, "bench.py")
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-        "data", "config", "roofline", "cpu_baseline"}
+        "data", "config", "roofline", "cpu_baseline", "sustained"}
 
 
 def _check(line, steps, warmup):
     d = json.loads(line)
     assert KEYS <= set(d)
     assert d["unit"] == "DoF/s" and d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f64"
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["dofs_per_gpu"] * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
     r = d["roofline"]
@@ -28,11 +28,15 @@ def _check(line, steps, warmup):
     assert r["operator_ms"] >= r["avg_launch_ms"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "DoF/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert f"{d['config']['dofs_per_gpu']} DoFs" in c["sample"]          # the CPU leg runs on the bench's own mesh
+    s = d["sustained"]
+    assert s["unit"] == "DoF/s" and s["value"] > 0 and s["iterations"] >= 1 and s["repetitions"] >= 1
     return d
 
 
 def test_bench_json_line_small_workload():
-    r = subprocess.run([sys.executable, BENCH, "--cells", "12", "12", "12", "--steps", "7", "--warmup", "2"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, BENCH, "--cells", "12", "12", "12", "--steps", "7", "--warmup", "2", "--sustained-iters", "20", "--sustained-reps", "2",
+                        "--cpu-budget", "2"], capture_output=True, text=True,
                        timeout=900, cwd=bp5_pkg.ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -1042,7 +1042,11 @@ def test_argument_validation():
     odd = torch.zeros(mesh.n_owned + 1, dtype=torch.float64, device="cuda:0")[1:]   # 8-byte but not 16-byte aligned
     assert L.bp5_vec_axpy(h, p(odd), 1.0, p(x), 4) == 1
     assert L.bp5_apply(h, None, p(x), p(x), 1) == 1
-    assert L.bp5_mf_set_apply_variant(h, 77) == 0 and L.bp5_apply(h, p(op.coef), p(x), p(op.initialize_dof_vector()), 1) == 1
+    # unknown variants and the timing-only ablation builds (wrong results by construction; they exist only in
+    # libbp5_timing.so) are refused by the product library when they are SET, not at the first apply
+    for bad_variant in (77, 21, 23, 41, 61, 80, 81, 85, 91, 93, 95, 97, 99, 73):
+        assert L.bp5_mf_set_apply_variant(h, bad_variant) == 1
+    assert L.bp5_mf_set_apply_variant(h, 0) == 0
     # a corrupt local_to_global is rejected on the host, before anything reaches the GPU
     from deal_and_ceed_on_gpu_amd import _lib
     bad = mesh.l2g.copy()

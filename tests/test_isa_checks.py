@@ -1,5 +1,6 @@
 """Static checks of the gfx950 ISA the library was built from (no GPU needed).  The device compile keeps its
 assembly (csrc/Makefile, --save-temps); __graft_entry__.build() produces it."""
+import glob
 import os
 import re
 import sys
@@ -8,15 +9,20 @@ import pytest
 
 import bp5_pkg
 
-ISA = os.path.join(bp5_pkg.ROOT, "deal-and-ceed-on-gpu_amd", "csrc", "bp5_device-hip-amdgcn-amd-amdhsa-gfx950.s")
+CSRC = os.path.join(bp5_pkg.ROOT, "deal-and-ceed-on-gpu_amd", "csrc")
+UNITS = ["bp5_device"] + [f"bp5_apply_p{d}" for d in range(1, 9)]   # the device translation units of libbp5.so (csrc/Makefile)
 sys.path.insert(0, os.path.join(bp5_pkg.ROOT, "tools"))
 
 
 def _isa():
-    assert os.path.exists(ISA), "device ISA missing: run __graft_entry__.build() (make -C deal-and-ceed-on-gpu_amd/csrc)"
+    """ISA files of every device translation unit, from the very compile that produced libbp5.so."""
+    files = [os.path.join(CSRC, f"{u}-hip-amdgcn-amd-amdhsa-gfx950.s") for u in UNITS]
     lib = os.path.join(bp5_pkg.ROOT, "deal-and-ceed-on-gpu_amd", "libbp5.so")
-    assert os.path.getmtime(ISA) <= os.path.getmtime(lib) + 1.0, "ISA is newer than libbp5.so: rebuild"
-    return ISA
+    for f in files:
+        assert os.path.exists(f), f"device ISA {f} missing: run __graft_entry__.build() (make -C deal-and-ceed-on-gpu_amd/csrc)"
+        assert os.path.getmtime(f) <= os.path.getmtime(lib) + 1.0, "ISA is newer than libbp5.so: rebuild"
+    assert sorted(files) == sorted(glob.glob(os.path.join(CSRC, "*-gfx950.s"))), "stale ISA files of units that no longer exist"
+    return files
 
 
 def test_no_barrier_is_reached_with_an_lds_write_in_flight():
@@ -24,7 +30,7 @@ def test_no_barrier_is_reached_with_an_lds_write_in_flight():
     __syncthreads() when the barrier is a loop header and the LDS write comes in through the back-edge (the
     accumulation rounds of the block kernel).  Every kernel of the library is checked on every path."""
     import check_lds_barrier
-    assert check_lds_barrier.main(_isa()) == 0
+    assert sum(check_lds_barrier.main(f) for f in _isa()) == 0
 
 
 def test_checker_detects_the_pattern():
@@ -41,7 +47,7 @@ def test_checker_detects_the_pattern():
 def test_default_operator_kernels_do_not_spill():
     """The p = 4 defaults (block kernel with packed indices / with run-length write-out only, pencil kernel) use no scratch and stay within the
     register budget of three waves per SIMD (168 VGPRs)."""
-    text = open(_isa()).read()
+    text = "".join(open(f).read() for f in _isa())
     want = {"apply_block_kernelILi4ELb0ELi32ELi1ELi288768E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi288768E": 168,
             "apply_block_kernelILi4ELb0ELi32ELi1ELi26624E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi26624E": 168,
             "apply_pencil_kernelILi4ELb0ELi4ELi25ELi1ELb1ELi0E": 168}
