@@ -144,6 +144,11 @@ def lib():
         "bp5_mf_set_comm": (i32, [vp, vp]),
         "bp5_comm_allreduce_sum": (i32, [vp, vp, sz]),
         "bp5_halo_gather": (i32, [vp, vp]),
+        "bp5_halo_gather_start": (i32, [vp, vp]),
+        "bp5_halo_gather_finish": (i32, [vp, vp]),
+        "bp5_halo_scatter_add_start": (i32, [vp, vp]),
+        "bp5_halo_scatter_add_finish": (i32, [vp, vp]),
+        "bp5_mf_set_overlap": (i32, [vp, i32]),
         "bp5_halo_scatter_add": (i32, [vp, vp]),
         "bp5_halo_zero_ghosts": (i32, [vp, vp]),
         "bp5_apply_distributed": (i32, [vp, vp, vp, vp, i32]),

@@ -124,11 +124,14 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   if (mf->h_st) hipHostFree(mf->h_st);
   for (hipEvent_t e : mf->ev_pool) hipEventDestroy(e);
   for (hipEvent_t e : mf->ev_solve) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : mf->ev_halo) if (e) hipEventDestroy(e);
+  if (mf->comm_stream) { hipStreamSynchronize(mf->comm_stream); hipStreamDestroy(mf->comm_stream); }
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile, q.wg_block};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile};
     for (void *x : pp) if (x) hipFree(x);
+    if (q.wg_blocks) { for (auto &w : *q.wg_blocks) hipFree(w.second); delete q.wg_blocks; }
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
   delete mf;
@@ -811,40 +814,99 @@ extern "C" int bp5_comm_allreduce_sum(bp5_mf *mf, double *buf, size_t n)
   NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, mf->comm->comm, mf->stream));
   return BP5_OK;
 }
+// Halo exchange.  The RCCL traffic runs on the handle's own communication stream, ordered against the compute stream by
+// events, so that cell work enqueued between a *_start and its *_finish overlaps the transfer (the reference:
+// update_ghost_values_start/finish, compress_start/finish inside cell_loop with overlap_communication_computation,
+// bp5/step-64.cu:241,274).  With overlap switched off (bp5_mf_set_overlap) everything stays on the compute stream.
+static int halo_streams(bp5_mf *mf)
+{
+  if (mf->comm_stream) return BP5_OK;
+  // highest priority: the stream then gets a hardware queue of its own (a plain second stream was seen to share the
+  // compute stream's queue -- in-order, no overlap at all: profiles/r2 c_*), and the short RCCL kernels are not queued
+  // behind the cell kernel's workgroups
+  int prio_lo = 0, prio_hi = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  HIP_TRY(hipStreamCreateWithPriority(&mf->comm_stream, hipStreamNonBlocking, prio_hi));
+  for (hipEvent_t &e : mf->ev_halo) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return BP5_OK;
+}
+extern "C" int bp5_mf_set_overlap(bp5_mf *mf, int on)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  mf->overlap = on != 0;
+  return BP5_OK;
+}
 // ghost gather: owners send their interface values (packed through send_indices), ghosts are
 // received straight into the vector's ghost range (contiguous per neighbour)
-extern "C" int bp5_halo_gather(bp5_mf *mf, double *v)
+extern "C" int bp5_halo_gather_start(bp5_mf *mf, double *v)
 {
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
   if (mf->neighbors.empty()) return BP5_OK;
   if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
+  HIP_TRY(hipSetDevice(mf->device));
+  BP5_TRY(halo_streams(mf));
   const uint32_t ns = mf->send_off.back();
   if (ns) {
     hipLaunchKernelGGL(pack_kernel, dim3((ns + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx, ns, v, mf->d_sendbuf);
     KERNEL_CHECK();
   }
+  hipStream_t cs = mf->overlap ? mf->comm_stream : mf->stream;
+  if (mf->overlap) { // the exchange starts once the values are packed (and everything before them on the compute stream is done)
+    HIP_TRY(hipEventRecord(mf->ev_halo[0], mf->stream));
+    HIP_TRY(hipStreamWaitEvent(cs, mf->ev_halo[0], 0));
+  }
   NCCL_TRY(ncclGroupStart());
   for (size_t k = 0; k < mf->neighbors.size(); ++k) {
     const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k], rc = mf->recv_off[k + 1] - mf->recv_off[k];
-    if (sc) NCCL_TRY(ncclSend(mf->d_sendbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
-    if (rc) NCCL_TRY(ncclRecv(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
+    if (sc) NCCL_TRY(ncclSend(mf->d_sendbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, cs));
+    if (rc) NCCL_TRY(ncclRecv(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, cs));
   }
   NCCL_TRY(ncclGroupEnd());
+  if (mf->overlap) HIP_TRY(hipEventRecord(mf->ev_halo[1], cs));
   return BP5_OK;
 }
+extern "C" int bp5_halo_gather_finish(bp5_mf *mf, double *v)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (mf->neighbors.empty()) return BP5_OK;
+  if (!mf->comm || !mf->comm_stream) return fail(BP5_ERR_INVALID, "bp5_halo_gather_finish without bp5_halo_gather_start");
+  if (mf->overlap) HIP_TRY(hipStreamWaitEvent(mf->stream, mf->ev_halo[1], 0)); // later compute work sees the ghosts
+  return BP5_OK;
+}
+extern "C" int bp5_halo_gather(bp5_mf *mf, double *v)
+{
+  BP5_TRY(bp5_halo_gather_start(mf, v));
+  return bp5_halo_gather_finish(mf, v);
+}
 // compress(add): ghost contributions travel back to the owners and are added; ghosts zeroed
-extern "C" int bp5_halo_scatter_add(bp5_mf *mf, double *v)
+extern "C" int bp5_halo_scatter_add_start(bp5_mf *mf, double *v)
 {
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
   if (mf->neighbors.empty()) return BP5_OK;
   if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
+  HIP_TRY(hipSetDevice(mf->device));
+  BP5_TRY(halo_streams(mf));
+  hipStream_t cs = mf->overlap ? mf->comm_stream : mf->stream;
+  if (mf->overlap) { // the ghost entries are complete at this point of the compute stream
+    HIP_TRY(hipEventRecord(mf->ev_halo[2], mf->stream));
+    HIP_TRY(hipStreamWaitEvent(cs, mf->ev_halo[2], 0));
+  }
   NCCL_TRY(ncclGroupStart());
   for (size_t k = 0; k < mf->neighbors.size(); ++k) {
     const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k], rc = mf->recv_off[k + 1] - mf->recv_off[k];
-    if (rc) NCCL_TRY(ncclSend(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
-    if (sc) NCCL_TRY(ncclRecv(mf->d_recvbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, mf->stream));
+    if (rc) NCCL_TRY(ncclSend(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, cs));
+    if (sc) NCCL_TRY(ncclRecv(mf->d_recvbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, cs));
   }
   NCCL_TRY(ncclGroupEnd());
+  if (mf->overlap) HIP_TRY(hipEventRecord(mf->ev_halo[3], cs));
+  return BP5_OK;
+}
+extern "C" int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (mf->neighbors.empty()) return BP5_OK;
+  if (!mf->comm || !mf->comm_stream) return fail(BP5_ERR_INVALID, "bp5_halo_scatter_add_finish without bp5_halo_scatter_add_start");
+  if (mf->overlap) HIP_TRY(hipStreamWaitEvent(mf->stream, mf->ev_halo[3], 0));
   for (size_t k = 0; k < mf->neighbors.size(); ++k) { // per neighbour: indices distinct -> race-free, fixed order
     const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k];
     if (!sc) continue;
@@ -854,22 +916,105 @@ extern "C" int bp5_halo_scatter_add(bp5_mf *mf, double *v)
   }
   return bp5_halo_zero_ghosts(mf, v);
 }
+extern "C" int bp5_halo_scatter_add(bp5_mf *mf, double *v)
+{
+  BP5_TRY(bp5_halo_scatter_add_start(mf, v));
+  return bp5_halo_scatter_add_finish(mf, v);
+}
 extern "C" int bp5_halo_zero_ghosts(bp5_mf *mf, double *v)
 {
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
   if (mf->n_ghost) HIP_TRY(hipMemsetAsync(v + mf->n_owned, 0, (size_t)mf->n_ghost * sizeof(double), mf->stream));
   return BP5_OK;
 }
+
+// The operator application in phases (MatrixFree::cell_loop with overlap_communication_computation, bp5/step-64.cu:241,274;
+// SURVEY 3.2 / Appendix C3): ghost gather in flight under the first part of the interior cells, then the cells that touch
+// ghosts, then the ghost contributions travel to their owners under the rest of the interior cells.  ONE kernel family is
+// chosen for the whole application; the block kernel runs its brick ranges with owner stores + partial slab and a single
+// combine pass at the end, so the result is bitwise the one of the unsplit launch.
+struct ApplyPhases {
+  bool block = false, set = false, overwrite = false;
+  bp5_mf::DevPlan *dp = nullptr;
+  int user_variant = 0;
+};
+static int phases_begin(bp5_mf *mf, double *dst, bool overwrite, ApplyPhases &ph)
+{
+  ph.user_variant = mf->apply_variant;
+  const int ev = effective_variant(mf, 0, mf->n_cells);
+  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49) && mf->degree == 4;
+  ph.overwrite = false;
+  if (ph.block) {
+    BP5_TRY(get_plan_raw(mf, -8, &ph.dp));
+    ph.set = overwrite && ph.dp->covers_all;
+    ph.overwrite = ph.set;
+    if (overwrite && !ph.set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    mf->defer_combine = true;
+    mf->apply_variant = ev; // every range takes the block kernel, however few bricks it holds
+  } else if (overwrite) // atomic kernels accumulate: one zero-fill, then every range adds
+    HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  return BP5_OK;
+}
+static int phases_range(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, ApplyPhases &ph)
+{
+  if (c1 <= c0) return BP5_OK;
+  return launch_apply(mf, coef, src, dst, c0, c1, ph.overwrite);
+}
+static int phases_end(bp5_mf *mf, double *dst, ApplyPhases &ph, int status)
+{
+  mf->defer_combine = false;
+  mf->apply_variant = ph.user_variant;
+  BP5_TRY(status);
+  return ph.block ? launch_combine(mf, ph.dp, dst, ph.set) : BP5_OK;
+}
+// interior cells [0, split) run under the ghost gather, [split, n_interior) under the scatter-add; split on a brick boundary
+static uint32_t interior_split(const bp5_mf *mf)
+{
+  const uint32_t half = mf->n_interior / 2;
+  if (mf->h_block_off.empty()) return half;
+  const auto it = std::lower_bound(mf->h_block_off.begin(), mf->h_block_off.end(), half);
+  return it == mf->h_block_off.end() || *it > mf->n_interior ? mf->n_interior : *it;
+}
+static int apply_overlapped(bp5_mf *mf, const double *coef, double *src, double *dst, bool overwrite)
+{
+  // block-kernel ranges must be unions of whole bricks: the generator emits interior and ghost-touching bricks separately;
+  // a mesh whose n_interior_cells cuts through a brick runs unsplit (the exchange is then not overlapped)
+  uint32_t b0, b1;
+  const bool aligned = mf->h_block_off.empty() || mf->n_interior == 0 || mf->n_interior == mf->n_cells ||
+                       block_aligned(mf, 0, mf->n_interior, &b0, &b1);
+  ApplyPhases ph;
+  BP5_TRY(bp5_halo_gather_start(mf, src));
+  int st = phases_begin(mf, dst, overwrite, ph);
+  if (st == BP5_OK && (!aligned || !mf->overlap)) {
+    st = bp5_halo_gather_finish(mf, src);
+    if (st == BP5_OK) st = phases_range(mf, coef, src, dst, 0, mf->n_cells, ph);
+    BP5_TRY(phases_end(mf, dst, ph, st));
+    return bp5_halo_scatter_add(mf, dst);
+  }
+  const uint32_t split = interior_split(mf);
+  if (st == BP5_OK) st = phases_range(mf, coef, src, dst, 0, split, ph);                 // under the gather
+  if (st == BP5_OK) st = bp5_halo_gather_finish(mf, src);
+  if (st == BP5_OK) st = phases_range(mf, coef, src, dst, mf->n_interior, mf->n_cells, ph); // cells that touch ghosts
+  // The ghost entries of dst are final only after the combine pass when the block kernel runs (ghost DoFs on brick faces
+  // go through the partial slab), so the block kernel sends them after the last range; the atomic kernels send them now,
+  // under the second part of the interior cells.
+  if (!ph.block) {
+    if (st == BP5_OK) st = bp5_halo_scatter_add_start(mf, dst);
+    if (st == BP5_OK) st = phases_range(mf, coef, src, dst, split, mf->n_interior, ph);
+    BP5_TRY(phases_end(mf, dst, ph, st));
+    return bp5_halo_scatter_add_finish(mf, dst);
+  }
+  if (st == BP5_OK) st = phases_range(mf, coef, src, dst, split, mf->n_interior, ph);
+  BP5_TRY(phases_end(mf, dst, ph, st));
+  return bp5_halo_scatter_add(mf, dst);
+}
 extern "C" int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src, double *dst, int zero_dst)
 {
-  if (!mf || !coef || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !src || !dst) return fail(BP5_ERR_INVALID, "null argument");
   if (src == dst) return fail(BP5_ERR_INVALID, "src and dst must differ");
   HIP_TRY(hipSetDevice(mf->device));
-  // stream order: ghost gather, all cells, scatter-add.  (Interior cells [0,n_interior) do not
-  // read ghosts; the overlapped 3-phase schedule of SURVEY 3.2 is a later optimisation.)
-  BP5_TRY(bp5_halo_gather(mf, src));
-  BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero_dst != 0));
-  BP5_TRY(bp5_halo_scatter_add(mf, dst));
+  if (mf->comm && !mf->neighbors.empty()) BP5_TRY(apply_overlapped(mf, coef, src, dst, zero_dst != 0));
+  else BP5_TRY(launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero_dst != 0));
   BP5_TRY(bp5_halo_zero_ghosts(mf, src));
   return bp5_copy_constrained(mf, src, dst);
 }
@@ -946,7 +1091,20 @@ struct ApplyProfile {
 static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof)
 {
   const bool dist = mf->comm && !mf->neighbors.empty(); // halo exchange: whenever there are neighbours (tests: a self neighbour)
-  if (dist) BP5_TRY(bp5_halo_gather(mf, src));
+  if (dist) { // phased application: the exchange overlaps the interior cells (apply_overlapped)
+    BP5_TRY(prof.mark(0));
+    BP5_TRY(prof.mark(1));
+    if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
+    const int st = apply_overlapped(mf, coef, src, dst, zero);
+    const bool marked = prof.on && mf->prof_mark == nullptr;
+    mf->prof_mark = nullptr;
+    BP5_TRY(st);
+    if (!marked) BP5_TRY(prof.mark(2));
+    BP5_TRY(prof.mark(3));
+    if (prof.on) prof.used += 4;
+    BP5_TRY(bp5_halo_zero_ghosts(mf, src));
+    return bp5_copy_constrained(mf, src, dst);
+  }
   // kernels that accumulate with atomics need a zeroed target (owner-scatter kernels define every entry themselves)
   const bool owner_scatter = variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells));
   BP5_TRY(prof.mark(0));
@@ -963,7 +1121,6 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   if (!marked) BP5_TRY(prof.mark(2));
   BP5_TRY(prof.mark(3));
   if (prof.on) prof.used += 4;
-  if (dist) { BP5_TRY(bp5_halo_scatter_add(mf, dst)); BP5_TRY(bp5_halo_zero_ghosts(mf, src)); }
   return bp5_copy_constrained(mf, src, dst);
 }
 

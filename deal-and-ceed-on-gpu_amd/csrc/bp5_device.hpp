@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <vector>
 
 using namespace bp5;
@@ -71,6 +72,11 @@ struct bp5_mf {
   std::vector<uint32_t> send_off, recv_off;
   double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
   bp5_comm *comm = nullptr;
+  // halo exchange on its own stream (overlap with interior cells): created on first use
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_halo[4] = {nullptr, nullptr, nullptr, nullptr}; // packed / gathered / ghosts ready / received
+  bool overlap = true;        // MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241)
+  bool defer_combine = false; // block kernel on cell ranges: partial slab now, ONE combine pass after the last range
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
@@ -92,8 +98,9 @@ struct bp5_mf {
     uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
     uint16_t *packed = nullptr;
     std::vector<double> h_cost;                       // [n_groups+1] prefix sum of the estimated cost of the blocks (pass units)
-    uint32_t *wg_block = nullptr;                     // cached ranges for (wg_n, wg_b0, wg_b1)
-    uint32_t wg_n = 0, wg_b0 = 0, wg_b1 = 0;
+    // block ranges of the persistent workgroups, one device array per (n_wg, first block, end block) ever launched: the
+    // interior / boundary ranges of the overlapped schedule alternate, nothing is freed or re-uploaded inside a solve
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t *> *wg_blocks = nullptr;
     uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
@@ -171,7 +178,10 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const bool sub_range = mf->blk_b1 > mf->blk_b0 && (mf->blk_b0 != 0 || mf->blk_b1 != dp->n_groups);
   bp.blk_begin = sub_range ? mf->blk_b0 : 0;
   if (sub_range) bp.n_blocks = mf->blk_b1 - mf->blk_b0;
-  if (sub_range && overwrite) return fail(BP5_ERR_INVALID, "a cell range cannot overwrite dst");
+  // ... unless the caller runs ALL blocks in several range launches and one combine pass after the last one
+  // (mf->defer_combine: the overlapped halo schedule): then every launch is the ordinary owner-store kernel
+  const bool atomic_shared = mf->block_shared_atomic || (sub_range && !mf->defer_combine);
+  if (sub_range && overwrite && !mf->defer_combine) return fail(BP5_ERR_INVALID, "a cell range cannot overwrite dst");
   // persistent grid: two workgroups per CU (LDS budget), a multiple of 8 for the XCD mapping
   if (!mf->n_cus) {
     hipDeviceProp_t prop;
@@ -186,18 +196,21 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   { // block ranges of the persistent workgroups: equal shares of the estimated COST (thin or partial bricks are cheaper per
     // block but dearer per cell than full ones), cached
     const uint32_t B0 = bp.blk_begin, B1 = bp.blk_begin + bp.n_blocks;
-    if (!dp->wg_block || dp->wg_n != n_wg || dp->wg_b0 != B0 || dp->wg_b1 != B1) {
+    if (!dp->wg_blocks) dp->wg_blocks = new std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t *>;
+    auto key = std::make_tuple(n_wg, B0, B1);
+    auto itw = dp->wg_blocks->find(key);
+    if (itw == dp->wg_blocks->end()) {
       std::vector<uint32_t> wb(n_wg + 1);
       const std::vector<double> &pc = dp->h_cost;
       const double c0 = pc[B0], total = pc[B1] - c0;
       for (uint32_t w = 0; w <= n_wg; ++w)
         wb[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + B1 + 1, c0 + total * w / n_wg - 1e-9) - pc.begin());
       wb[0] = B0; wb[n_wg] = B1;
-      if (dp->wg_block) { HIP_TRY(hipStreamSynchronize(mf->stream)); HIP_TRY(hipFree(dp->wg_block)); dp->wg_block = nullptr; }
-      BP5_TRY(upload(&dp->wg_block, wb.data(), wb.size()));
-      dp->wg_n = n_wg; dp->wg_b0 = B0; dp->wg_b1 = B1;
+      uint32_t *dev = nullptr;
+      BP5_TRY(upload(&dev, wb.data(), wb.size()));
+      itw = dp->wg_blocks->emplace(key, dev).first;
     }
-    bp.wg_block = dp->wg_block;
+    bp.wg_block = itw->second;
   }
   bp.stamps = nullptr;
   if (ABL & 4096) {
@@ -216,7 +229,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   const dim3 grid(n_wg), block(256);
-  if (mf->block_shared_atomic || sub_range) {
+  if (atomic_shared) {
     // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
     if (set && dp->n_shared) {
       hipLaunchKernelGGL(zero_indexed_kernel, dim3((dp->n_shared + 255) / 256), dim3(256), 0, mf->stream, dp->sh_dof, dp->n_shared, dst);
@@ -256,6 +269,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     for (int k = 0; k < 7; ++k) fprintf(stderr, "[bp5 stamps]   %-26s %5.1f %%  %8.0f cycles/pass\n", nm[k], 100.0 * tot[k] / all, tot[k] / tot[8]);
   }
   if (ABL & 1023) return BP5_OK; // (1024 and above are real modes) timing-only ablation builds skip the combine pass (1024/2048/8192 are real modes)
+  if (mf->defer_combine) return BP5_OK; // the caller runs launch_combine after its last range
   return launch_combine(mf, dp, dst, set);
 }
 

@@ -132,6 +132,10 @@ class MatrixFree:
         """BP5_GEOM_MERGED6 (reference representation, default) or BP5_GEOM_AFFINE (affine meshes)."""
         _lib.check(_lib.lib().bp5_mf_set_geometry_mode(self.handle, int(mode)))
 
+    def set_overlap(self, on=True):
+        """== AdditionalData::overlap_communication_computation (bp5/step-64.cu:241), default on."""
+        _lib.check(_lib.lib().bp5_mf_set_overlap(self.handle, 1 if on else 0))
+
     def set_apply_variant(self, v):
         _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
 
@@ -301,6 +305,19 @@ class Vector:
 
     def update_ghost_values(self):
         _lib.check(_lib.lib().bp5_halo_gather(self.mf.handle, _ptr(self.values)))
+
+    def update_ghost_values_start(self):
+        _lib.check(_lib.lib().bp5_halo_gather_start(self.mf.handle, _ptr(self.values)))
+
+    def update_ghost_values_finish(self):
+        _lib.check(_lib.lib().bp5_halo_gather_finish(self.mf.handle, _ptr(self.values)))
+
+    def compress_start(self):
+        """== compress_start(VectorOperation::add)"""
+        _lib.check(_lib.lib().bp5_halo_scatter_add_start(self.mf.handle, _ptr(self.values)))
+
+    def compress_finish(self):
+        _lib.check(_lib.lib().bp5_halo_scatter_add_finish(self.mf.handle, _ptr(self.values)))
 
     def compress_add(self):
         """== compress(VectorOperation::add)"""

@@ -259,11 +259,28 @@ int bp5_mf_set_comm(bp5_mf *mf, bp5_comm *comm);
  * (replaces cudaMemcpy D2H + MPI_Allreduce, bp5/solver.h:488-494) */
 int bp5_comm_allreduce_sum(bp5_mf *mf, double *buf, size_t n);
 /* == src.update_ghost_values_start/finish, dst.compress_start/finish(add), zero_out_ghosts
- *    (inside cell_loop, bp5/step-64.cu:274) */
+ *    (inside cell_loop, bp5/step-64.cu:274).
+ *    *_start: the owners' values are packed on the handle's stream, then the RCCL send/recv group runs on the handle's own
+ *    communication stream (ordered by events); *_finish: the handle's stream waits for the transfer (scatter-add: and adds
+ *    the received contributions to the owned entries, ghosts zeroed).  Work enqueued on the handle's stream between a start
+ *    and its finish overlaps the transfer; it must not touch the entries in flight (gather: the ghost range of v;
+ *    scatter-add: the ghost range of v and nothing else).  One exchange of each kind may be in flight per handle.
+ *    bp5_halo_gather / bp5_halo_scatter_add = start immediately followed by finish. */
+int bp5_halo_gather_start(bp5_mf *mf, double *v);
+int bp5_halo_gather_finish(bp5_mf *mf, double *v);
+int bp5_halo_scatter_add_start(bp5_mf *mf, double *v);
+int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v);
 int bp5_halo_gather(bp5_mf *mf, double *v);
 int bp5_halo_scatter_add(bp5_mf *mf, double *v);
 int bp5_halo_zero_ghosts(bp5_mf *mf, double *v);
-/* distributed vmult with the reference's 3-phase overlap */
+/* == MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241; default on, as in the reference):
+ *    off = the exchange stays on the handle's stream and the cell loop runs unsplit */
+int bp5_mf_set_overlap(bp5_mf *mf, int on);
+/* distributed vmult == PoissonOperator::vmult on more than one rank (bp5/step-64.cu:263-276 with the cell_loop of :274):
+ *    ghost gather started; first part of the interior cells [0, n_interior_cells) underneath it; gather finished; the cells
+ *    that touch ghosts; ghost contributions sent to their owners (atomic kernels: under the rest of the interior cells; the
+ *    block kernel: after its single combine pass, which completes the ghost entries) and added; ghosts of src zeroed;
+ *    Dirichlet copy.  Same kernels and, with the block kernel, bitwise the same result as the unsplit application. */
 int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src, double *dst, int zero_dst);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -217,12 +217,16 @@ def merged_metric(mesh, N, D, w, kappa=kappa_none):
 
 
 # ----------------------------------------------------------------------------- operator (A.4)
-def apply_cells(mesh, coef, N, D, src, chunk=4096):
-    """dst = sum_cells P^T B^T S B P src  (no Dirichlet step), bp5/step-64.cu:147-194."""
+def apply_cells(mesh, coef, N, D, src, chunk=4096, cell_range=None, dst=None):
+    """dst = sum_cells P^T B^T S B P src  (no Dirichlet step), bp5/step-64.cu:147-194.
+    cell_range = (begin, end) restricts the loop to those cells and dst (if given) is accumulated into: one colour of
+    MatrixFree::cell_loop's overlapped schedule (bp5/step-64.cu:241,274)."""
     n = mesh.n
-    dst = np.zeros(mesh.n_dofs)
-    for c0 in range(0, mesh.n_cells, chunk):
-        c1 = min(mesh.n_cells, c0 + chunk)
+    if dst is None:
+        dst = np.zeros(mesh.n_dofs)
+    lo, hi = (0, mesh.n_cells) if cell_range is None else cell_range
+    for c0 in range(lo, hi, chunk):
+        c1 = min(hi, c0 + chunk)
         idx = mesh.l2g[c0:c1].astype(np.int64)
         u = src[idx].reshape(c1 - c0, n, n, n)
         g0, g1, g2 = _grad_ref(u, N, D)

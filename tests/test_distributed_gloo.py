@@ -1,9 +1,11 @@
 """world_size-2/3 rehearsal of the multi-GPU path on CPU (gloo).
 
 What runs here is the library's own slab partition + halo plan (bp5_mesh_create_brick) and the
-exact exchange sequence of bp5_apply_distributed / bp5_cg_solve (ghost gather -> all cells ->
-scatter-add to owners -> zero ghosts -> Dirichlet copy; dot products over OWNED entries with one
-all-reduce), with the oracle standing in for the HIP kernels and gloo for RCCL.  It pins the
+exact exchange sequence of bp5_apply_distributed / bp5_cg_solve (ghost gather started -> first part
+of the interior cells -> gather finished -> ghost-touching cells -> scatter-add started -> rest of
+the interior cells -> scatter-add finished -> zero ghosts -> Dirichlet copy: the reference's
+overlap_communication_computation schedule, bp5/step-64.cu:241,274; dot products over OWNED entries
+with one all-reduce), with the oracle standing in for the HIP kernels and gloo for RCCL.  It pins the
 partition, ownership and halo-plan semantics the C++ RCCL path relies on; the RCCL calls
 themselves are exercised on the GPU box with a 1-rank communicator (test_gpu_parity.py) and by the
 driver's multi-GPU bench."""
@@ -41,8 +43,8 @@ def _free_port():
     return port
 
 
-def _halo_gather(m, v):
-    """owners send send_indices[...] values; ghosts are received into the ghost range"""
+def _halo_gather_start(m, v):
+    """owners send send_indices[...] values; ghosts are received into the ghost range (bp5_halo_gather_start)"""
     reqs, bufs = [], []
     for k in range(m.n_neighbors):
         nb = int(m.neighbor_rank[k])
@@ -56,6 +58,11 @@ def _halo_gather(m, v):
             t = torch.empty(r1 - r0, dtype=torch.float64)
             bufs.append((t, r0, r1))
             reqs.append(dist.irecv(t, nb))
+    return reqs, bufs
+
+
+def _halo_gather_finish(m, v, pending):
+    reqs, bufs = pending
     for q in reqs:
         q.wait()
     for b in bufs:
@@ -64,8 +71,12 @@ def _halo_gather(m, v):
             v[m.n_owned + r0:m.n_owned + r1] = t.numpy()
 
 
-def _halo_scatter_add(m, v):
-    """ghost contributions go back to the owner and are added (compress(add)); ghosts zeroed"""
+def _halo_gather(m, v):
+    _halo_gather_finish(m, v, _halo_gather_start(m, v))
+
+
+def _halo_scatter_add_start(m, v):
+    """ghost contributions go back to the owner (bp5_halo_scatter_add_start: the ghost entries are final here)"""
     reqs, bufs = [], []
     for k in range(m.n_neighbors):
         nb = int(m.neighbor_rank[k])
@@ -79,6 +90,12 @@ def _halo_scatter_add(m, v):
             t = torch.empty(s1 - s0, dtype=torch.float64)
             bufs.append((t, s0, s1))
             reqs.append(dist.irecv(t, nb))
+    return reqs, bufs
+
+
+def _halo_scatter_add_finish(m, v, pending):
+    """... and are added (compress(add)); ghosts zeroed"""
+    reqs, bufs = pending
     for q in reqs:
         q.wait()
     for b in bufs:
@@ -86,6 +103,20 @@ def _halo_scatter_add(m, v):
             t, s0, s1 = b
             np.add.at(v, m.send_indices[s0:s1].astype(np.int64), t.numpy())
     v[m.n_owned:] = 0.0
+
+
+def _halo_scatter_add(m, v):
+    _halo_scatter_add_finish(m, v, _halo_scatter_add_start(m, v))
+
+
+def _interior_split(m):
+    """== interior_split() of csrc/bp5_device.hip: half of the interior cells, rounded up to a brick boundary"""
+    half = m.n_interior_cells // 2
+    if m.cell_block_offsets is None:
+        return half
+    off = np.asarray(m.cell_block_offsets)
+    i = int(np.searchsorted(off, half, side="left"))
+    return int(off[i]) if i < off.size and off[i] <= m.n_interior_cells else m.n_interior_cells
 
 
 def _allreduce(x):
@@ -106,10 +137,15 @@ def _worker(rank, world, port, p, cells, quad, amp, numbering, block, iters, out
         coef = O.merged_metric(lm, N, D, w, O.kappa_step64)
         no, c = m.n_owned, m.constrained.astype(np.int64)
 
-        def vmult(src):                       # == bp5_apply_distributed(zero_dst = 1)
-            _halo_gather(m, src)
-            dst = O.apply_cells(lm, coef, N, D, src)
-            _halo_scatter_add(m, dst)
+        def vmult(src):                       # == bp5_apply_distributed(zero_dst = 1): apply_overlapped() of csrc/bp5_device.hip
+            split, n_int = _interior_split(m), m.n_interior_cells
+            pending = _halo_gather_start(m, src)
+            dst = O.apply_cells(lm, coef, N, D, src, cell_range=(0, split))                     # under the ghost gather
+            _halo_gather_finish(m, src, pending)
+            O.apply_cells(lm, coef, N, D, src, cell_range=(n_int, m.n_cells), dst=dst)          # the cells that touch ghosts
+            pending = _halo_scatter_add_start(m, dst)
+            O.apply_cells(lm, coef, N, D, src, cell_range=(split, n_int), dst=dst)              # under the scatter-add
+            _halo_scatter_add_finish(m, dst, pending)
             src[no:] = 0.0
             dst[c] = src[c]
             dst[no:] = 0.0

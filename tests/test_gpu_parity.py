@@ -890,6 +890,30 @@ def test_halo_exchange_through_rccl_with_a_self_neighbour():
     refw[no:] = 0.0
     assert L.bp5_halo_scatter_add(h, ptr(w)) == 0
     assert torch.equal(w, refw)
+    # the start / finish split (update_ghost_values_start/finish, compress_start/finish): compute enqueued between the
+    # two halves overlaps the transfer on the handle's communication stream and must not disturb it
+    v2, w2 = ref.clone(), w.clone()
+    v2[no:] = -1.0
+    w2[no:] = refw[torch.from_numpy(send_idx.astype(np.int64)).cuda()]
+    refw2 = w2.clone()
+    refw2[torch.from_numpy(send_idx.astype(np.int64)).cuda()] += refw2[no:]
+    refw2[no:] = 0.0
+    busy = torch.zeros(1 << 22, dtype=torch.float64, device="cuda:0")
+    assert L.bp5_halo_gather_start(h, ptr(v2)) == 0
+    for _ in range(4):
+        assert L.bp5_vec_fill(h, ptr(busy), 1.0, busy.numel()) == 0
+    assert L.bp5_halo_gather_finish(h, ptr(v2)) == 0
+    assert L.bp5_halo_scatter_add_start(h, ptr(w2)) == 0
+    for _ in range(4):
+        assert L.bp5_vec_fill(h, ptr(busy), 2.0, busy.numel()) == 0
+    assert L.bp5_halo_scatter_add_finish(h, ptr(w2)) == 0
+    assert torch.equal(v2, ref) and torch.equal(w2, refw2)
+    assert L.bp5_mf_set_overlap(h, 0) == 0                    # same calls with the exchange on the compute stream
+    v3 = ref.clone()
+    v3[no:] = -1.0
+    assert L.bp5_halo_gather_start(h, ptr(v3)) == 0 and L.bp5_halo_gather_finish(h, ptr(v3)) == 0
+    assert torch.equal(v3, ref)
+    assert L.bp5_mf_set_overlap(h, 1) == 0
     # the whole distributed application against the same steps by hand
     src = torch.rand(no + ng, dtype=torch.float64, device="cuda:0", generator=g)
     src[no:] = 0.0
@@ -959,13 +983,44 @@ def test_block_kernel_behind_the_halo_exchange(variant):
         assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(s_in), ptr(d), 1) == 0
         outs.append(d)
     assert float((outs[1] - outs[0]).abs().max()) < 1e-12 * float(outs[0].abs().max())
+    # the overlapped 3-phase schedule (default, the reference's overlap_communication_computation, bp5/step-64.cu:241:
+    # exchange on the communication stream under the interior bricks, ghost-touching bricks after it) against the
+    # sequential one (overlap off: exchange and one unsplit launch on the compute stream).  Same kernels, same
+    # per-brick order, ONE combine pass after the last range: the block kernel's result is bitwise identical.
+    assert L.bp5_mf_set_overlap(h, 0) == 0
+    d_seq = op.initialize_dof_vector()
+    d_seq.fill_(float("nan"))
+    s_in = src.clone()
+    assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(s_in), ptr(d_seq), 1) == 0
+    if variant == 56:
+        assert torch.equal(d_seq, outs[1])
+    else:
+        assert float((d_seq - outs[1]).abs().max()) < 1e-13 * float(outs[1].abs().max())
+    assert L.bp5_mf_set_overlap(h, 1) == 0
+    d_acc = torch.full_like(d_seq, 0.25)                  # accumulate mode (zero_dst = 0) through the phases
+    d_acc[no:] = 0.0                                      # (ghost entries of dst hold contributions only: zero on entry)
+    s_in = src.clone()
+    assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(s_in), ptr(d_acc), 0) == 0
+    c = torch.from_numpy(m1.constrained.astype(np.int64)).cuda()
+    want_acc = d_seq + 0.25
+    want_acc[no:] = 0.0
+    want_acc[c] = src[c]
+    assert float((d_acc - want_acc).abs().max()) < 1e-12 * float(want_acc.abs().max())
     b = op.assemble_rhs()
-    x = op.initialize_dof_vector()
-    ctl = pkg.IterationNumberControl(10, 0.0)
-    pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
-    Ax, xin = op.initialize_dof_vector(), x.clone()
-    assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(xin), ptr(Ax), 1) == 0
-    assert abs(float(torch.linalg.norm((Ax - b)[:no])) - ctl.last_value()) < 1e-9 * ctl.initial_value()
+    xs = []
+    for overlap in (1, 0):
+        assert L.bp5_mf_set_overlap(h, overlap) == 0
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(10, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        Ax, xin = op.initialize_dof_vector(), x.clone()
+        assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(xin), ptr(Ax), 1) == 0
+        assert abs(float(torch.linalg.norm((Ax - b)[:no])) - ctl.last_value()) < 1e-9 * ctl.initial_value()
+        xs.append(x)
+    if variant == 56:
+        assert torch.equal(xs[0], xs[1])                  # the whole solve is bitwise independent of the schedule
+    else:
+        assert float((xs[0] - xs[1]).abs().max()) < 1e-11 * float(xs[1].abs().max())
     op.mf_data.synchronize()
     op.mf_data.close()
     comm.close()
