@@ -85,6 +85,9 @@ class CGResult(C.Structure):
                 ("apply_ms_avg", C.c_double), ("apply_launches", C.c_int), ("operator_ms_avg", C.c_double)]
 
 
+VMULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # bp5_vmult_fn(ctx, dst, src)
+
+
 def lib():
     """Load libbp5.so; fails loudly if it has not been built (no fallback of any kind)."""
     global _LIB
@@ -149,10 +152,12 @@ def lib():
         "bp5_halo_scatter_add_start": (i32, [vp, vp]),
         "bp5_halo_scatter_add_finish": (i32, [vp, vp]),
         "bp5_mf_set_overlap": (i32, [vp, i32]),
+        "bp5_mf_set_cg_fusion": (i32, [vp, i32]),
         "bp5_halo_scatter_add": (i32, [vp, vp]),
         "bp5_halo_zero_ghosts": (i32, [vp, vp]),
         "bp5_apply_distributed": (i32, [vp, vp, vp, vp, i32]),
         "bp5_cg_solve": (i32, [vp, vp, vp, vp, vp, C.POINTER(CGParams), C.POINTER(CGResult)]),
+        "bp5_cg_solve_operator": (i32, [vp, VMULT_FN, vp, vp, vp, vp, C.POINTER(CGParams), C.POINTER(CGResult)]),
         "bp5_event_create": (i32, [C.POINTER(vp)]),
         "bp5_event_record": (i32, [vp, vp]),
         "bp5_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f64)]),

@@ -77,6 +77,8 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   }
   BP5_TRY(upload(&mf->d_coords, d->node_coords_host, nloc * 3));
   BP5_TRY(upload(&mf->d_constrained, d->constrained_host, d->n_constrained));
+  mf->h_constrained.assign(nloc, false);
+  for (uint32_t s = 0; s < d->n_constrained; ++s) mf->h_constrained[d->constrained_host[s]] = true;
   std::vector<double> tv;
   pack_tab(tab, tv);  BP5_TRY(upload(&mf->d_tab, tv.data(), tv.size()));
   pack_tab(tabg, tv); BP5_TRY(upload(&mf->d_tab_gauss, tv.data(), tv.size()));
@@ -166,7 +168,7 @@ static bool product_variant(int degree, int v)
   if (v == 10 || v == 50 || v == 70) return true;
   switch (degree) {
     case 1: case 3: return v == 1;
-    case 4: return (v >= 1 && v <= 6) || (v >= 11 && v <= 14) || (v >= 48 && v <= 59) || v == 71 || v == 72;
+    case 4: return (v >= 1 && v <= 6) || (v >= 11 && v <= 14) || (v >= 48 && v <= 61) || v == 71 || v == 72;
     case 5: return v >= 1 && v <= 3;
     case 6: return v >= 1 && v <= 5;
     case 7: case 8: return (v >= 1 && v <= 3) || v == 5;
@@ -184,6 +186,12 @@ extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
 }
 
 static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1);
+extern "C" int bp5_mf_set_cg_fusion(bp5_mf *mf, int on)
+{
+  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  mf->cg_fusion = on != 0;
+  return BP5_OK;
+}
 extern "C" int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups)
 {
   if (!mf || max_workgroups < 0) return fail(BP5_ERR_INVALID, "bad argument");
@@ -338,6 +346,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
   auto it = mf->plans.find(key);
   if (it == mf->plans.end()) {
     TeamPlanHost h;
+    if (key < 0 && mf->n_local() >= (1ull << 30)) return fail(BP5_ERR_UNSUPPORTED, "block plan needs fewer than 2^30 local DoFs");
     if (key > 0) BP5_TRY(build_team_plan(mf->h_l2g.data(), mf->n_cells, mf->n3, mf->n_local(), key, h));
     else if (!mf->h_block_off.empty())
       BP5_TRY(build_team_plan(mf->h_l2g.data(), mf->n_cells, mf->n3, mf->n_local(), 0, h, mf->h_block_off.data(),
@@ -353,12 +362,15 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       run_off.assign(h.off.size(), 0);
       for (size_t g = 0; g + 1 < h.off.size(); ++g) {
         uint32_t start = h.off[g];
-        for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i)
-          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1 || i - start == (1u << BLOCK_PACK_OFF_BITS)) {
+        for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i) {
+          const bool con = mf->h_constrained[h.dofs[i] & 0x7fffffffu];
+          if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1 || i - start == (1u << BLOCK_PACK_OFF_BITS) ||
+              con != (bool)mf->h_constrained[h.dofs[i - 1] & 0x7fffffffu]) {
             start = i;
             runs.push_back(i - h.off[g]);
-            runs.push_back(h.dofs[i]);
+            runs.push_back(h.dofs[i] | (con ? BLOCK_DOF_CONSTRAINED : 0u)); // bit 31 exclusive (from dofs), bit 30 Dirichlet
           }
+        }
         run_off[g + 1] = (uint32_t)(runs.size() / 2);
         dp.max_runs = std::max(dp.max_runs, run_off[g + 1] - run_off[g]);
       }
@@ -427,11 +439,12 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       const size_t ns = h.sh_dof.size();
       for (size_t i = 0; i < ns; ++i) {
         const uint32_t b = h.sh_off[i], e = h.sh_off[i + 1];
-        bool cont = i > 0 && h.sh_dof[i] == h.sh_dof[i - 1] + 1 && (e - b) == (h.sh_off[i] - h.sh_off[i - 1]);
+        bool cont = i > 0 && h.sh_dof[i] == h.sh_dof[i - 1] + 1 && (e - b) == (h.sh_off[i] - h.sh_off[i - 1]) &&
+                    mf->h_constrained[h.sh_dof[i]] == mf->h_constrained[h.sh_dof[i - 1]];
         for (uint32_t q = 0; cont && q < e - b; ++q) cont = h.sh_slot[b + q] == h.sh_slot[h.sh_off[i - 1] + q] + 1;
         if (!cont) {
           start.push_back((uint32_t)i);
-          dof0.push_back(h.sh_dof[i]);
+          dof0.push_back(h.sh_dof[i] | (mf->h_constrained[h.sh_dof[i]] ? 0x80000000u : 0u)); // bit 31: Dirichlet run
           soff.push_back((uint32_t)slots.size());
           slots.insert(slots.end(), h.sh_slot.begin() + b, h.sh_slot.begin() + e);
         }
@@ -474,10 +487,22 @@ int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
 int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
 {
   if (!dp->n_shared) return BP5_OK;
+  if (mf->fuse.on && !(set && dp->cr_tile && !mf->combine_csr)) return fail(BP5_ERR_INVALID, "fused dot products need the run-length combine pass in overwrite mode");
   if (mf->prof_mark) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
   const dim3 cg((dp->n_shared + 255) / 256);
   if (dp->cr_tile && !mf->combine_csr) {
-    const CombineRuns cr{dp->cr_start, dp->cr_dof0, dp->cr_soff, dp->cr_slots, dp->cr_tile, dp->n_shared};
+    CombineRuns cr{};
+    cr.start = dp->cr_start; cr.dof0 = dp->cr_dof0; cr.soff = dp->cr_soff; cr.slots = dp->cr_slots; cr.tile_run = dp->cr_tile;
+    cr.n_shared = dp->n_shared;
+    if (mf->fuse.on) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
+      cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
+      cr.n_owned = mf->n_owned; cr.n_tiles = cg.x; cr.cg_state = mf->d_st;
+      const uint32_t grid = std::min<uint32_t>(cg.x, (uint32_t)MAXBLK - mf->fuse.n_cols);
+      hipLaunchKernelGGL((combine_runs_kernel<false, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      KERNEL_CHECK();
+      mf->fuse.n_cols += grid;
+      return BP5_OK;
+    }
     if (set) hipLaunchKernelGGL(combine_runs_kernel<false>, cg, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     else hipLaunchKernelGGL(combine_runs_kernel<true>, cg, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     KERNEL_CHECK();
@@ -546,7 +571,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 static bool variant_overwrites(const bp5_mf *mf, int ev)
 {
   const int v = ev % 100;
-  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 59)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 61)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
 }
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
@@ -942,7 +967,7 @@ static int phases_begin(bp5_mf *mf, double *dst, bool overwrite, ApplyPhases &ph
 {
   ph.user_variant = mf->apply_variant;
   const int ev = effective_variant(mf, 0, mf->n_cells);
-  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49) && mf->degree == 4;
+  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61) && mf->degree == 4;
   ph.overwrite = false;
   if (ph.block) {
     BP5_TRY(get_plan_raw(mf, -8, &ph.dp));
@@ -1088,7 +1113,11 @@ struct ApplyProfile {
 };
 
 // A.vmult(h, d) inside the solvers: dst already zero on entry when zeroed == true
-static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof)
+// fuse_r != nullptr (merged CG on the packed block kernel, one rank's worth of cells, D == 1): the operator's write-out and
+// combine pass also form the v-dependent dot products of update_b (bp5/solver.h:142-311) and apply the Dirichlet copy; the
+// partial sums land in d_partials, *n_cols columns of them
+static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof, const double *fuse_r = nullptr,
+                        uint32_t *n_cols = nullptr)
 {
   const bool dist = mf->comm && !mf->neighbors.empty(); // halo exchange: whenever there are neighbours (tests: a self neighbour)
   if (dist) { // phased application: the exchange overlaps the interior cells (apply_overlapped)
@@ -1114,13 +1143,16 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   }
   BP5_TRY(prof.mark(1));
   if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
+  if (fuse_r) { mf->fuse.on = true; mf->fuse.p = src; mf->fuse.r = fuse_r; mf->fuse.n_cols = 0; }
   const int st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero);
+  if (fuse_r) { *n_cols = mf->fuse.n_cols; mf->fuse = bp5_mf::Fuse{}; }
   const bool marked = prof.on && mf->prof_mark == nullptr;
   mf->prof_mark = nullptr;
   BP5_TRY(st);
   if (!marked) BP5_TRY(prof.mark(2));
   BP5_TRY(prof.mark(3));
   if (prof.on) prof.used += 4;
+  if (fuse_r) return BP5_OK; // Dirichlet DoFs were written by the fused write-out
   return bp5_copy_constrained(mf, src, dst);
 }
 
@@ -1132,10 +1164,12 @@ static int poll_state(bp5_mf *mf)
   return BP5_OK;
 }
 
-extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, const double *b, double *x, const bp5_cg_params *prm,
-                            bp5_cg_result *res)
+// cg.solve(A, x, b, preconditioner): the solvers need nothing of A but vmult (bp5/solver.h:25-30,377,475).  user == nullptr:
+// the built-in Poisson operator (coef); otherwise the caller's operator through its callback.
+static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void *user_ctx, const double *diag, const double *b, double *x,
+                         const bp5_cg_params *prm, bp5_cg_result *res)
 {
-  if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !b || !x || !prm || !res) return fail(BP5_ERR_INVALID, "null argument");
+  if (!mf || (!user && !coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !b || !x || !prm || !res) return fail(BP5_ERR_INVALID, "null argument");
   if (prm->max_iter < 0) return fail(BP5_ERR_INVALID, "max_iter < 0");
   if (prm->variant != BP5_CG_PLAIN && prm->variant != BP5_CG_MERGED) return fail(BP5_ERR_INVALID, "unknown CG variant");
   if (!aligned16(b) || !aligned16(x) || (diag && !aligned16(diag))) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
@@ -1151,6 +1185,18 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
     while (mf->ev_pool.size() < want) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
   }
   const hipEvent_t ev0 = mf->ev_solve[0], ev1 = mf->ev_solve[1];
+  // h = A d.  dst is fully defined by the call (the reference zeroes it in update_a* for its atomic scatter)
+  auto vmult = [&](double *src, double *dst, const double *fuse_r, uint32_t *n_cols) -> int {
+    if (!user) return solver_vmult(mf, coef, src, dst, true, prof, fuse_r, n_cols);
+    BP5_TRY(prof.mark(0));
+    BP5_TRY(prof.mark(1));
+    const int st = user(user_ctx, dst, src);
+    if (st != BP5_OK) return fail(st, "the operator's vmult callback reported a failure");
+    BP5_TRY(prof.mark(2));
+    BP5_TRY(prof.mark(3));
+    if (prof.on) prof.used += 4;
+    return BP5_OK;
+  };
   // scalars: tolerance + iteration cap
   mf->h_sc[SC_TOL] = prm->abs_tol;
   HIP_TRY(hipMemcpyAsync(mf->d_sc + SC_TOL, mf->h_sc + SC_TOL, sizeof(double), hipMemcpyHostToDevice, s));
@@ -1171,7 +1217,7 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
     hipLaunchKernelGGL(cg_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
     for (int it = 1; it <= prm->max_iter; ++it) {
-      BP5_TRY(solver_vmult(mf, coef, d, h, true, prof));
+      BP5_TRY(vmult(d, h, nullptr, nullptr));
       hipLaunchKernelGGL(dot_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials);
       hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_DH, mf->d_st);
       KERNEL_CHECK();
@@ -1196,15 +1242,29 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
     hipLaunchKernelGGL(cgm_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
+    // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
+    bool fused = false;
+    if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty()) && mf->degree == 4 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
+        effective_variant(mf, 0, mf->n_cells) == 56) {
+      bp5_mf::DevPlan *dp = nullptr;
+      BP5_TRY(get_plan_raw(mf, -8, &dp));
+      fused = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);
+    }
     int it = 1;
     for (; it <= prm->max_iter; ++it) {
       if (it == 1) hipLaunchKernelGGL(cgm_update_kernel<0>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
       else if (it % 2 == 0) hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
       else hipLaunchKernelGGL(cgm_update_kernel<2>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
       KERNEL_CHECK();
-      BP5_TRY(solver_vmult(mf, coef, d, h, true, prof)); // overwrite mode: v needs no zeroing (the reference zeroes it in update_a*)
-      hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
-      hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
+      if (fused) {
+        uint32_t n_cols = 0;
+        BP5_TRY(vmult(d, h, g, &n_cols));
+        hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_R0, mf->d_st);
+      } else {
+        BP5_TRY(vmult(d, h, nullptr, nullptr));
+        hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
+        hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
+      }
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
       hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
@@ -1246,4 +1306,16 @@ extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, 
   }
   if (mf->h_st[ST_BREAKDOWN]) status = fail(BP5_ERR_BREAKDOWN, "CG breakdown: p.Ap is zero or NaN");
   return status;
+}
+
+extern "C" int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, const double *b, double *x, const bp5_cg_params *prm,
+                            bp5_cg_result *res)
+{
+  return cg_solve_impl(mf, coef, nullptr, nullptr, diag, b, x, prm, res);
+}
+extern "C" int bp5_cg_solve_operator(bp5_mf *mf, bp5_vmult_fn vmult, void *ctx, const double *diag, const double *b, double *x,
+                                     const bp5_cg_params *prm, bp5_cg_result *res)
+{
+  if (!vmult) return fail(BP5_ERR_INVALID, "null vmult callback");
+  return cg_solve_impl(mf, nullptr, vmult, ctx, diag, b, x, prm, res);
 }

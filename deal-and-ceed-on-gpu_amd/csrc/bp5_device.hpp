@@ -76,6 +76,7 @@ struct bp5_mf {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_halo[4] = {nullptr, nullptr, nullptr, nullptr}; // packed / gathered / ghosts ready / received
   bool overlap = true;        // MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241)
+  bool cg_fusion = true;      // SolverCGFullMerge: dot products inside the block kernel's write-out when the plan allows
   bool defer_combine = false; // block kernel on cell ranges: partial slab now, ONE combine pass after the last range
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
@@ -105,6 +106,13 @@ struct bp5_mf {
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     bool covers_all = false;
   };
+  std::vector<bool> h_constrained;   // per local DoF: Dirichlet DoF (run tables carry the flag)
+  // fused CG dot products (SolverCGFullMerge on the block kernel): set by the solver around ONE operator application
+  struct Fuse {
+    bool on = false;
+    const double *p = nullptr, *r = nullptr;
+    uint32_t n_cols = 0; // columns of d_partials written so far (block kernel workgroups, then the combine pass)
+  } fuse;
   std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
   struct DevMarch { uint32_t *team_off = nullptr, *entries = nullptr; uint32_t n_teams = 0; };
   std::map<int, DevMarch> march_plans; // keyed by cells per team
@@ -164,7 +172,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -CPT, &dp));
   const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
-  const size_t lds = ((size_t)CPT * tile_cs + dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
+  const size_t lds = ((size_t)CPT * tile_cs + ((ABL & 524288) ? 2 : 1) * (size_t)dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
   if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 64 runs per block: packed indices unavailable");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
@@ -212,6 +220,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     }
     bp.wg_block = itw->second;
   }
+  bp.cg_r = mf->fuse.r; bp.dot_partials = mf->d_partials; bp.n_owned = mf->n_owned; bp.cg_state = mf->d_st;
   bp.stamps = nullptr;
   if (ABL & 4096) {
     if (!mf->d_stamps) HIP_TRY(hipMalloc((void **)&mf->d_stamps, 4096 * 16 * sizeof(unsigned long long)));
@@ -229,7 +238,12 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   const dim3 grid(n_wg), block(256);
-  if (atomic_shared) {
+  if constexpr ((ABL & 1048576) != 0) { // fused CG dot products: whole range, overwrite mode, every DoF touched
+    if (!set || atomic_shared || sub_range || mf->defer_combine || !mf->fuse.on) return fail(BP5_ERR_INVALID, "fused dot products need one whole-range overwrite launch");
+    if (n_wg > (uint32_t)MAXBLK / 2) return fail(BP5_ERR_UNSUPPORTED, "too many workgroups for the partial-sum rows");
+    mf->fuse.n_cols = n_wg;
+  }
+  if constexpr ((ABL & 1048576) == 0) if (atomic_shared) {
     // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
     if (set && dp->n_shared) {
       hipLaunchKernelGGL(zero_indexed_kernel, dim3((dp->n_shared + 255) / 256), dim3(256), 0, mf->stream, dp->sh_dof, dp->n_shared, dst);
@@ -251,7 +265,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_SET, ABL>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
-  } else {
+  } else if constexpr ((ABL & 1048576) == 0) {
     auto kern = apply_block_kernel<P, COLL, LPC, SC_OWNER_ADD, ABL>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
@@ -528,11 +542,28 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
     }
     // 48 = 56 with the per-DoF CSR combine kernel instead of the run-length one (A/B)
     // 49 = 56 with run-length write-out but without packed indices (A/B)
-    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
+    // 60 = 56 with the brick's src staged once in LDS (cells gather from LDS; needs the packed indices)
+    // 61 = 56 with non-temporal metric loads (A/B: the once-read metric stream then evicts less of a brick's src from L2)
+    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56 || variant == 60 || variant == 61) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
         struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
         mf->combine_csr = variant == 48;
         bp5_mf::DevPlan *dp_ = nullptr;
         BP5_TRY(get_plan_raw(mf, -8, &dp_));
+        if (variant == 60) {
+          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 60 needs packed indices (<= 64 runs per cell block)");
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite);
+        }
+        if (variant == 61) {
+          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 61 needs packed indices (<= 64 runs per cell block)");
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite);
+        }
+        if (mf->fuse.on) { // the solver asked for the fused dot products (only ever with the packed default shape)
+          if (!dp_->packed || variant != 56) return fail(BP5_ERR_INVALID, "fused dot products need the packed block kernel");
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite);
+        }
         if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);

@@ -990,6 +990,10 @@ __device__ __forceinline__ void load_pencil_idx(const T *base, int ab, T (&v)[n]
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int BLOCK_MAX_RUNS = 128;
+// run table entry "first DoF": bit 31 = the run's DoFs are touched by this block only (owner stores), bit 30 = Dirichlet DoFs
+// (builds with fused dot products write src there: copy_constrained_values folded into the write-out); DoF indices < 2^30
+constexpr uint32_t BLOCK_DOF_MASK = 0x3fffffffu, BLOCK_DOF_CONSTRAINED = 0x40000000u;
+constexpr int MAXBLK_DOTS = 2048;      // row length of the dot-product partial sums (== MAXBLK of the streaming kernels)
 constexpr int BLOCK_PACK_OFF_BITS = 10;                             // packed index = run << 10 | offset
 constexpr int BLOCK_PACK_MAX_RUNS = 1 << (16 - BLOCK_PACK_OFF_BITS); // 64
 struct BlockPlan {
@@ -1015,6 +1019,11 @@ struct BlockPlan {
   const uint32_t *runs;       // [2 * run_off[n_blocks]]
   uint32_t max_list;          // longest block list (the accumulator's size in LDS)
   unsigned long long *stamps; // diagnostic builds only: [n_wg][16] cycle sums per phase (never read by kernels)
+  // builds with ABL & 1048576 (fused CG dot products, SolverCGFullMerge's update_b, bp5/solver.h:142-311): src == p, dst == v
+  const double *cg_r;         // residual vector r
+  double *dot_partials;       // [7][MAXBLK] row k, column = workgroup: p.v, v.v, r.v, r.r (rows 4-6 = rows 2, 1, 3: D == 1)
+  uint32_t n_owned;           // dot products run over owned entries only
+  const int *cg_state;        // st[ST_DONE] != 0: the solve has stopped, the launch is a no-op (iterate frozen)
 };
 
 // register set of one pass (cell ids, positions, gathered values, metric)
@@ -1062,6 +1071,11 @@ struct BlockPass {
   // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
   // workgroup needs a third of the tile memory: 4x4x4 accumulator + tiles = 47 KB -> three workgroups per CU
   static constexpr bool PACK = (ABL & 262144) != 0; // packed (run, offset) indices, decoded through the LDS run table
+  // STAGE: the brick's src values are staged ONCE in an LDS array indexed like the accumulator (block start: coalesced loads
+  // along the runs of the brick's sorted DoF list); the cells gather from LDS -- no global gather instructions, every src
+  // entry of a brick crosses HBM/L2 once instead of once per cell that touches it
+  static constexpr bool STAGE = (ABL & 524288) != 0;
+  static_assert(!STAGE || (PACK && (ABL & 16384)), "LDS-staged src needs packed indices and the run table");
   static constexpr bool SEQ = (ABL & 8192) != 0;
   static_assert(!SEQ || WAVE_LOCAL, "sequential tiles need wave-local cells");
   static constexpr int TILE_CS = SEQ ? (n * L::PS + 3) : L::CS; // doubles per cell slot
@@ -1105,14 +1119,17 @@ struct BlockPass {
   }
   // PACK: r.ps holds the packed entries of the pass; turn them into list slots (kept in r.ps for the accumulation) and
   // DoF indices through the run table `rt` of the pass's block, and start the gather
-  static __device__ __forceinline__ void decode_and_gather(const ApplyArgs &a, R &r, const uint32_t *rt)
+  static __device__ __forceinline__ void decode_and_gather(const ApplyArgs &a, R &r, const uint32_t *rt, const double *staged = nullptr)
   {
 #pragma unroll
     for (int k = 0; k < n; ++k) {
       const uint32_t e = r.ps[k], run = e >> BLOCK_PACK_OFF_BITS, off = e & ((1u << BLOCK_PACK_OFF_BITS) - 1u);
-      const uint32_t dof = (rt[BLOCK_MAX_RUNS + run] & 0x7fffffffu) + off;
       r.ps[k] = (uint16_t)(rt[run] + off);
-      r.u[k] = (ABL & 4) ? 1e-9 * dof : a.src[dof];
+      if constexpr (STAGE) r.u[k] = staged[r.ps[k]];
+      else {
+        const uint32_t dof = (rt[BLOCK_MAX_RUNS + run] & BLOCK_DOF_MASK) + off;
+        r.u[k] = (ABL & 4) ? 1e-9 * dof : a.src[dof];
+      }
     }
   }
   static __device__ __forceinline__ void issue_gather(const ApplyArgs &a, R &r)
@@ -1516,9 +1533,18 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   // persistent workgroup w owns the contiguous block range [b0,b1); workgroups that share an XCD
   // (blockIdx % 8, speed only) own neighbouring ranges
   const uint32_t w = (blockIdx.x & 7u) * (bp.n_wg >> 3) + (blockIdx.x >> 3);
+  // DOTS: the write-out also accumulates the merged CG's v-dependent dot products over the DoFs it stores (and writes src
+  // instead of the sum on Dirichlet DoFs); brick-surface DoFs are handled the same way by combine_runs_kernel<.., true>
+  constexpr bool DOTS = (ABL & 1048576) != 0;
+  static_assert(!DOTS || (((ABL & 16384) != 0) && SCATTER == SC_OWNER_SET), "fused dot products: run-length write-out, overwrite mode");
+  double ds[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (DOTS) { if (bp.cg_state[0]) return; }
   uint32_t b = bp.wg_block[w];
   const uint32_t b1 = bp.wg_block[w + 1];
-  if (b >= b1) return;
+  if (b >= b1) {
+    if constexpr (DOTS) { if (t < 7) bp.dot_partials[t * MAXBLK_DOTS + blockIdx.x] = 0.0; } // an idle workgroup still owns a column
+    return;
+  }
   uint32_t gp = bp.pass_off[b];
   const uint32_t gp_end = bp.pass_off[b1];
   uint32_t boundary = bp.pass_off[b + 1];
@@ -1529,7 +1555,9 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   // two LDS tables (block parity: a wave may still be writing out block b while another one enters b + 1) right
   // before the write-out barrier, and every thread walks it forward for its slots -- no list loads in the write-out
   constexpr bool RUNS = (ABL & 16384) != 0;
-  uint32_t *const run_tab = reinterpret_cast<uint32_t *>(acc + bp.max_list);
+  constexpr bool STAGE = BP::STAGE;
+  double *const staged = acc + bp.max_list; // STAGE: src values of the current brick, indexed like acc
+  uint32_t *const run_tab = reinterpret_cast<uint32_t *>(acc + (STAGE ? 2 : 1) * (size_t)bp.max_list);
   uint32_t r0 = RUNS ? bp.run_off[b] : 0u;
   int n_runs = RUNS ? (int)(bp.run_off[b + 1] - r0) : 0;
   uint32_t run_slot = 0, run_dof = 0;
@@ -1545,6 +1573,24 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   __syncthreads();
 
   auto entry = [&](uint32_t pass) { return bp.pass_cell[(uint64_t)(pass < gp_end ? pass : gp_end - 1) * CPT + slot]; };
+  // STAGE: fill staged[0, m_) with the src values of the brick whose run table rt_ (n_runs_ runs) is in LDS: thread t takes the
+  // slot pairs (2t, 2t+1) + 2 TEAM j and walks the table forward, consecutive lanes read consecutive DoFs of a run
+  auto enter_block = [&](const uint32_t *rt_, int n_runs_, int m_) {
+    int r = 0;
+    for (int i = 2 * t; i < m_; i += 2 * TEAM) {
+      while (r + 1 < n_runs_ && (int)rt_[r + 1] <= i) ++r;
+      const uint32_t g = (rt_[BLOCK_MAX_RUNS + r] & BLOCK_DOF_MASK) + (uint32_t)(i - (int)rt_[r]);
+      const bool run_ends = r + 1 < n_runs_ && (int)rt_[r + 1] == i + 1;
+      if (i + 1 < m_ && !run_ends) {
+        const bp5_d2u v = *reinterpret_cast<const bp5_d2u *>(a.src + g);
+        staged[i] = v.x;
+        staged[i + 1] = v.y;
+      } else {
+        staged[i] = a.src[g];
+        if (i + 1 < m_) staged[i + 1] = a.src[rt_[BLOCK_MAX_RUNS + r + 1] & BLOCK_DOF_MASK]; // first slot of the next run
+      }
+    }
+  };
 
   // two register sets, used alternately (loop unrolled by two): the loads of pass q+1 are issued
   // at the top of pass q and first waited for inside pass q+1
@@ -1562,7 +1608,11 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       rt0[BLOCK_MAX_RUNS + t] = bp.runs[2 * (r0 + t) + 1];
     }
     __syncthreads();
-    BP::decode_and_gather(a, A, rt0);
+    if constexpr (STAGE) {
+      enter_block(rt0, n_runs, m);
+      __syncthreads();
+    }
+    BP::decode_and_gather(a, A, rt0, staged);
   } else
     BP::issue_gather(a, A);
 
@@ -1610,12 +1660,21 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     const double v = acc[i];
     acc[i] = 0.0; // re-arm for the next block (invariant: the accumulator is all zero between blocks)
     if (g & 0x80000000u) {
-      if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[g & 0x7fffffffu] = v; }
+      const uint32_t gi = g & BLOCK_DOF_MASK;
+      if constexpr (DOTS) {
+        const double pi = a.src[gi];
+        const double vi = (g & BLOCK_DOF_CONSTRAINED) ? pi : v; // copy_constrained_values (bp5/step-64.cu:275)
+        __builtin_nontemporal_store(vi, a.dst + gi);
+        if (gi < bp.n_owned) {
+          const double ri = bp.cg_r[gi];
+          ds[0] += pi * vi; ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri;
+        }
+      } else if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[gi] = v; }
       else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
-        if constexpr (ABL & 65536) a.dst[g & 0x7fffffffu] = v;
-        else __builtin_nontemporal_store(v, a.dst + (g & 0x7fffffffu));
+        if constexpr (ABL & 65536) a.dst[gi] = v;
+        else __builtin_nontemporal_store(v, a.dst + gi);
       }
-      else a.dst[g & 0x7fffffffu] += v;
+      else a.dst[gi] += v;
     } else {
       if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
       else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + g, v);
@@ -1629,8 +1688,21 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     acc[i] = 0.0;
     acc[i + 1] = 0.0;
     if (g & 0x80000000u) {
-      double *d = a.dst + (g & 0x7fffffffu);
-      if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
+      const uint32_t gi = g & BLOCK_DOF_MASK;
+      double *d = a.dst + gi;
+      if constexpr (DOTS) {
+        const bp5_d2u pv = *reinterpret_cast<const bp5_d2u *>(a.src + gi);
+        const bool con = (g & BLOCK_DOF_CONSTRAINED) != 0;
+        const double w0 = con ? pv.x : v0, w1 = con ? pv.y : v1;
+        __builtin_nontemporal_store(bp5_d2u{w0, w1}, reinterpret_cast<bp5_d2u *>(d));
+        if (gi + 1 < bp.n_owned) {
+          const bp5_d2u rv = *reinterpret_cast<const bp5_d2u *>(bp.cg_r + gi);
+          ds[0] += pv.x * w0 + pv.y * w1; ds[1] += w0 * w0 + w1 * w1; ds[2] += rv.x * w0 + rv.y * w1; ds[3] += rv.x * rv.x + rv.y * rv.y;
+        } else if (gi < bp.n_owned) { // the pair straddles the end of the owned range
+          const double ri = bp.cg_r[gi];
+          ds[0] += pv.x * w0; ds[1] += w0 * w0; ds[2] += ri * w0; ds[3] += ri * ri;
+        }
+      } else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
         if constexpr (ABL & 65536) { d[0] = v0; d[1] = v1; }
         else __builtin_nontemporal_store(bp5_d2u{v0, v1}, reinterpret_cast<bp5_d2u *>(d));
       } else {
@@ -1704,8 +1776,14 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
           r0 = nx_r0;
           n_runs = (int)(nx_r1 - nx_r0);
         }
+        if constexpr (STAGE) {
+          // the next brick's table was parked before the write-out barrier; every pass of the finished brick has read its
+          // staged values (same barrier), so the array can be refilled now; the cells of the next pass read it after the barrier
+          enter_block(run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), n_runs, m);
+          __syncthreads();
+        }
       }
-      // no barrier here: the next pass starts with tile work and reaches the accumulation barrier before it
+      // no barrier here (unstaged builds): the next pass starts with tile work and reaches the accumulation barrier before it
       // touches the accumulator again
     }
     ++gp;
@@ -1719,7 +1797,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     finish_pass();
     BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
-    if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS)); // b: block of the next pass
+    if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged); // b: block of the next pass
     A.ent = entA2;
     prefetch_list();
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
@@ -1727,8 +1805,25 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev);
     finish_pass();
     BP5_STAMP(6)
-    if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS)); }
+    if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged); }
     B.ent = entB2;
+  }
+  if constexpr (DOTS) {
+    // block reduction in a fixed order (wave shuffles, then the four waves through LDS): bitwise reproducible for a fixed grid
+    __syncthreads(); // the tiles are free: every pass of this workgroup is done
+    double *red = lds;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = ds[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if ((t & 63) == 0) red[k * 4 + (t >> 6)] = v;
+    }
+    __syncthreads();
+    if (t < 7) {
+      const int k = t < 4 ? t : (t == 4 ? 2 : t == 5 ? 1 : 3); // D == 1: r.Dv = r.v, v.Dv = v.v, r.Dr = r.r
+      bp.dot_partials[t * MAXBLK_DOTS + blockIdx.x] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+    }
   }
   if constexpr (ABL & 4096) {
     if (t == 0) {
@@ -2006,33 +2101,71 @@ __global__ void __launch_bounds__(256) combine_kernel(const uint32_t *sh_dof, co
 // finds its run there.  Same summation order as combine_kernel (groups in ascending order): bitwise identical results,
 // about half the bytes (no per-DoF index arrays).
 struct CombineRuns {
-  const uint32_t *start, *dof0, *soff, *slots, *tile_run;
+  const uint32_t *start, *dof0, *soff, *slots, *tile_run; // dof0 bit 31: the run's DoFs are Dirichlet DoFs
   uint32_t n_shared;
+  // DOTS builds (fused CG dot products, see apply_block_kernel): the launch is a fixed grid walking the tiles
+  const double *cg_p, *cg_r;
+  double *dot_partials;    // [7][MAXBLK]; this launch writes the columns [dot_col0, dot_col0 + gridDim.x)
+  uint32_t dot_col0, n_owned, n_tiles;
+  const int *cg_state;
 };
-template <bool ADD>
-__global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const double *partial, double *dst)
+template <bool ADD, bool DOTS = false>
+static __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const double *partial, double *dst)
 {
   __shared__ uint32_t s_start[258], s_dof0[257], s_soff[258];
-  const uint32_t r_lo = cr.tile_run[blockIdx.x], r_hi = cr.tile_run[blockIdx.x + 1]; // inclusive range, r_hi - r_lo <= 256
-  const uint32_t cnt = r_hi - r_lo + 1;
-  for (uint32_t j = threadIdx.x; j <= cnt; j += 256) {
-    s_start[j] = cr.start[r_lo + j];
-    s_soff[j] = cr.soff[r_lo + j];
-    if (j < cnt) s_dof0[j] = cr.dof0[r_lo + j];
+  __shared__ double s_red[4][4];
+  double ds[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (DOTS) { if (cr.cg_state[0]) return; }
+  for (uint32_t tile = blockIdx.x; tile < (DOTS ? cr.n_tiles : blockIdx.x + 1); tile += gridDim.x) {
+    if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
+    const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= 256
+    const uint32_t cnt = r_hi - r_lo + 1;
+    for (uint32_t j = threadIdx.x; j <= cnt; j += 256) {
+      s_start[j] = cr.start[r_lo + j];
+      s_soff[j] = cr.soff[r_lo + j];
+      if (j < cnt) s_dof0[j] = cr.dof0[r_lo + j];
+    }
+    __syncthreads();
+    const uint32_t i = tile * 256u + threadIdx.x;
+    if (i >= cr.n_shared) continue;
+    uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_start[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
+    double s = 0.0; // (a DoF no cell touches has no slot: its sum is zero)
+    if (b < e) {
+      s = partial[cr.slots[b] + j];
+      for (uint32_t q = b + 1; q < e; ++q) s += partial[cr.slots[q] + j];
+    }
+    const uint32_t g = (s_dof0[lo] & 0x7fffffffu) + j;
+    if constexpr (DOTS) {
+      const double pi = cr.cg_p[g];
+      const double vi = (s_dof0[lo] & 0x80000000u) ? pi : s; // copy_constrained_values (bp5/step-64.cu:275)
+      dst[g] = vi;
+      if (g < cr.n_owned) {
+        const double ri = cr.cg_r[g];
+        ds[0] += pi * vi; ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri;
+      }
+    } else if (ADD) dst[g] += s;
+    else dst[g] = s;
   }
-  __syncthreads();
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= cr.n_shared) return;
-  uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (s_start[mid] <= i) lo = mid; else hi = mid;
+  if constexpr (DOTS) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = ds[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) s_red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+      const int t = threadIdx.x, k = t < 4 ? t : (t == 4 ? 2 : t == 5 ? 1 : 3); // D == 1
+      cr.dot_partials[t * MAXBLK_DOTS + cr.dot_col0 + blockIdx.x] = (s_red[k][0] + s_red[k][1]) + (s_red[k][2] + s_red[k][3]);
+    }
   }
-  const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
-  double s = partial[cr.slots[b] + j];
-  for (uint32_t q = b + 1; q < e; ++q) s += partial[cr.slots[q] + j];
-  const uint32_t g = s_dof0[lo] + j;
-  if (ADD) dst[g] += s; else dst[g] = s;
 }
 
 static __global__ void __launch_bounds__(256) zero_indexed_kernel(const uint32_t *idx, uint32_t n, double *dst)

@@ -136,6 +136,10 @@ class MatrixFree:
         """== AdditionalData::overlap_communication_computation (bp5/step-64.cu:241), default on."""
         _lib.check(_lib.lib().bp5_mf_set_overlap(self.handle, 1 if on else 0))
 
+    def set_cg_fusion(self, on=True):
+        """SolverCGFullMerge: dot products inside the block kernel's write-out (default) or as a separate kernel."""
+        _lib.check(_lib.lib().bp5_mf_set_cg_fusion(self.handle, 1 if on else 0))
+
     def set_apply_variant(self, v):
         _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
 
@@ -364,6 +368,13 @@ class IterationNumberControl(SolverControl):
     (bp5/step-64.cu:443-445)."""
 
 
+class _DeviceArray:
+    """__cuda_array_interface__ carrier: lets torch alias device memory the library owns (the solvers' work vectors)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
 class _SolverBase:
     variant = CG_PLAIN
 
@@ -371,15 +382,37 @@ class _SolverBase:
         self.control, self.check_every, self.profile = control, check_every, profile
 
     def solve(self, A, x, b, preconditioner=None):
-        """== cg.solve(A, x, b, preconditioner), bp5/step-64.cu:450-453,492-495.  x0 = 0."""
+        """== cg.solve(A, x, b, preconditioner), bp5/step-64.cu:450-453,492-495.  x0 = 0.
+        A PoissonOperator runs entirely inside bp5_cg_solve; any other object with `mf_data` (vector layout, stream) and
+        `vmult(dst, src)` is solved through bp5_cg_solve_operator -- the solvers need nothing of A but vmult
+        (bp5/solver.h:25-30,377,475)."""
         mf = A.mf_data
         x, b = _vals(x), _vals(b)
         diag = _vals(preconditioner.get_vector()) if preconditioner is not None else None
         prm = _lib.CGParams(self.variant, self.control.max_steps, self.control.tolerance, self.check_every,
                             1 if self.profile else 0)
         res = _lib.CGResult()
-        status = _lib.lib().bp5_cg_solve(mf.handle, _ptr(A.coef), _ptr(diag, mf.n_owned) if diag is not None else None,
-                                         _ptr(b, mf.n_local), _ptr(x, mf.n_local), C.byref(prm), C.byref(res))
+        dptr = _ptr(diag, mf.n_owned) if diag is not None else None
+        if isinstance(A, PoissonOperator):
+            status = _lib.lib().bp5_cg_solve(mf.handle, _ptr(A.coef), dptr, _ptr(b, mf.n_local), _ptr(x, mf.n_local), C.byref(prm), C.byref(res))
+        else:
+            torch, failure = _torch(), []
+
+            def view(p):
+                return torch.as_tensor(_DeviceArray(p, mf.n_local), device=f"cuda:{mf.device}")
+
+            def callback(_ctx, dst, src):      # enqueues on the current stream; no exception may cross the C boundary
+                try:
+                    A.vmult(view(dst), view(src))
+                    return 0
+                except Exception as e:         # noqa: BLE001
+                    failure.append(e)
+                    return 1
+
+            cb = _lib.VMULT_FN(callback)
+            status = _lib.lib().bp5_cg_solve_operator(mf.handle, cb, None, dptr, _ptr(b, mf.n_local), _ptr(x, mf.n_local), C.byref(prm), C.byref(res))
+            if failure:
+                raise failure[0]
         c = self.control
         c._last_step, c._last_value, c._initial_value = res.iterations, res.residual, res.initial_residual
         c.solve_ms, c.apply_ms_avg, c.apply_launches = res.solve_ms, res.apply_ms_avg, res.apply_launches

@@ -5,6 +5,8 @@
 //
 //   bp5_step64 check <degree> <nx> <ny> <nz> <deform> <prefix>   functor path vs fused path; dumps vectors
 //   bp5_step64 bench <degree> <n> <iterations> <repetitions>     prints pcg-standard / pcg-merged / vmult lines
+//   bp5_step64 helmholtz <degree> <n> <prefix>                   HelmholtzProblem::solve of step-64/step-64.cu on n^3 cells of the
+//                                                                unit cube: the functor operator inside the library's CG solvers
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -191,6 +193,37 @@ public:
   bool do_zero_out;
 };
 
+// ---- step-64's HelmholtzOperator (step-64/step-64.cu:226-300): owns the MatrixFree object and the coefficient array, applies the
+// user functor through cell_loop.  It has NO coef(): the solvers treat it as a foreign operator and only ever call vmult.
+template <int dim, int fe_degree>
+class HelmholtzOperator {
+public:
+  explicit HelmholtzOperator(const bp5_mesh_view &mv)
+  {
+    bp5_mf_desc d{};
+    d.dim = dim; d.degree = fe_degree; d.quadrature = BP5_QUAD_GAUSS; d.coefficient = BP5_COEF_ONE;
+    d.n_cells = mv.n_cells; d.n_interior_cells = mv.n_interior_cells; d.n_owned = mv.n_owned; d.n_ghost = mv.n_ghost;
+    d.local_to_global_host = mv.local_to_global_host; d.node_coords_host = mv.node_coords_host;
+    d.constrained_host = mv.constrained_host; d.n_constrained = mv.n_constrained;
+    mf_data.reinit(d);
+    check(bp5_vec_alloc((size_t)mv.n_cells * Utilities::pow(fe_degree + 1, dim), &coef));
+    mf_data.evaluate_coefficients(VaryingCoefficient<dim, fe_degree>(coef)); // step-64/step-64.cu:249-251
+  }
+  ~HelmholtzOperator() { bp5_vec_free(coef); }
+  void vmult(DeviceVector &dst, const DeviceVector &src) const
+  { // step-64/step-64.cu:283-300: dst = 0; cell_loop; copy_constrained_values
+    dst = 0.;
+    mf_data.cell_loop(LocalHelmholtz<dim, fe_degree>(coef), static_cast<const double *>(src.get_values()), dst.get_values());
+    mf_data.copy_constrained_values(static_cast<const double *>(src.get_values()), dst.get_values());
+  }
+  void initialize_dof_vector(DeviceVector &v) const { mf_data.initialize_dof_vector(v); }
+  bp5_mf *handle() const { return mf_data.handle(); }
+  CUDAWrappers::MatrixFree<dim, double> mf_data;
+
+private:
+  double *coef = nullptr;
+};
+
 static std::vector<double> download(const double *d, size_t n)
 {
   std::vector<double> h(n);
@@ -360,6 +393,44 @@ static int run_bench(uint32_t ncell, int n_iterations, int n_repetitions)
   return 0;
 }
 
+static void dump(const std::string &path, const std::vector<double> &v);
+// HelmholtzProblem<dim, fe_degree>::run for ONE cycle (step-64/step-64.cu:505-530,602-616,634-663): n^3 cells of the unit cube,
+// f == 1, zero Dirichlet values, a(x) = 10 / (0.05 + 2 |x|^2), identity preconditioner, tolerance 1e-12 ||b||, at most n_dofs
+// iterations; prints the iteration counts and the L2 norm of the solution for SolverCG and SolverCGFullMerge.
+template <int fe_degree>
+static int run_helmholtz(uint32_t ncell, const std::string &prefix)
+{
+  constexpr int dim = 3;
+  bp5_mesh_desc md{};
+  md.degree = fe_degree; md.cells[0] = md.cells[1] = md.cells[2] = ncell; md.h = 1.0 / ncell; md.n_ranks = 1;
+  bp5_mesh *mesh;
+  check(bp5_mesh_create_brick(&md, &mesh));
+  bp5_mesh_view mv;
+  check(bp5_mesh_view_get(mesh, &mv));
+  HelmholtzOperator<dim, fe_degree> system_matrix_dev(mv);
+  DeviceVector solution_dev, system_rhs_dev;
+  system_matrix_dev.initialize_dof_vector(solution_dev);
+  system_matrix_dev.initialize_dof_vector(system_rhs_dev);
+  check(bp5_assemble_rhs(system_matrix_dev.handle(), system_rhs_dev.get_values())); // (phi_i, 1), constrained rows 0: step-64.cu:443-481
+  printf("   Number of active cells:       %u\n   Number of degrees of freedom: %llu\n", mv.n_cells, (unsigned long long)mv.n_global_dofs);
+  const size_t n = mv.n_owned;
+  for (int merged = 0; merged < 2; ++merged) {
+    SolverControl solver_control((unsigned int)system_rhs_dev.size(), 1e-12 * system_rhs_dev.l2_norm());
+    solution_dev = 0.;
+    if (merged) { SolverCGFullMerge cg(solver_control); cg.solve(system_matrix_dev, solution_dev, system_rhs_dev, DiagonalMatrix()); }
+    else { SolverCG cg(solver_control); cg.solve(system_matrix_dev, solution_dev, system_rhs_dev, DiagonalMatrix()); }
+    double norm = 0;
+    check(bp5_l2_norm_solution(system_matrix_dev.handle(), solution_dev.get_values(), &norm));
+    printf("  %s: Solved in %u iterations.\n  solution norm: %.10g\n", merged ? "SolverCGFullMerge" : "SolverCG", solver_control.last_step(), norm);
+    printf("helmholtz_%s_iterations %u\nhelmholtz_%s_norm %.12e\nhelmholtz_%s_residual %.6e\n", merged ? "merged" : "plain", solver_control.last_step(),
+           merged ? "merged" : "plain", norm, merged ? "merged" : "plain", solver_control.last_value());
+    dump(prefix + (merged ? "_helmholtz_x_merged.bin" : "_helmholtz_x_plain.bin"), download(solution_dev.get_values(), n));
+  }
+  dump(prefix + "_helmholtz_b.bin", download(system_rhs_dev.get_values(), n));
+  bp5_mesh_destroy(mesh);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   try {
@@ -372,6 +443,12 @@ int main(int argc, char **argv)
         case 3: return run_check<3>(nx, ny, nz, deform, argv[7]);
         case 4: return run_check<4>(nx, ny, nz, deform, argv[7]);
       }
+    } else if (argc >= 5 && !strcmp(argv[1], "helmholtz")) {
+      switch (atoi(argv[2])) {
+        case 2: return run_helmholtz<2>(atoi(argv[3]), argv[4]);
+        case 3: return run_helmholtz<3>(atoi(argv[3]), argv[4]);
+        case 4: return run_helmholtz<4>(atoi(argv[3]), argv[4]);
+      }
     } else if (argc >= 6 && !strcmp(argv[1], "bench")) {
       const int p = atoi(argv[2]);
       switch (p) {
@@ -379,7 +456,7 @@ int main(int argc, char **argv)
         case 5: return run_bench<5>(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
       }
     }
-    fprintf(stderr, "usage: %s check <2|3|4> nx ny nz deform prefix | bench <4|5> n iterations repetitions\n", argv[0]);
+    fprintf(stderr, "usage: %s check <2|3|4> nx ny nz deform prefix | bench <4|5> n iterations repetitions | helmholtz <2|3|4> n prefix\n", argv[0]);
     return 2;
   } catch (const std::exception &e) {
     // same shape as the reference's top-level handler, bp5/step-64.cu:735-759

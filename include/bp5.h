@@ -314,6 +314,22 @@ typedef struct {
 int bp5_cg_solve(bp5_mf *mf, const double *coef, const double *diag, const double *b, double *x,
                  const bp5_cg_params *params, bp5_cg_result *result_host);
 
+/* The same solvers for ANY operator: cg.solve(A, x, b, preconditioner) uses nothing of A but A.vmult(dst, src)
+ * (bp5/solver.h:25-30,377,475; the reference solves step-64's Helmholtz operator with them, step-64/step-64.cu:505-530).
+ * The callback must ENQUEUE dst = A src on the handle's stream (no host synchronisation needed), define every owned entry
+ * of dst (Dirichlet rows included), may use the ghost range of src and dst as scratch, and returns BP5_OK or an error code
+ * (which aborts the solve and is returned).  `mf` supplies the vector layout (n_owned), the stream, the communicator for
+ * the dot products and the work vectors; b, x, diag as for bp5_cg_solve. */
+typedef int (*bp5_vmult_fn)(void *ctx, double *dst, double *src);
+int bp5_cg_solve_operator(bp5_mf *mf, bp5_vmult_fn vmult, void *ctx, const double *diag, const double *b, double *x,
+                          const bp5_cg_params *params, bp5_cg_result *result_host);
+
+/* BP5_CG_MERGED on the packed block kernel (p = 4, cell bricks, one rank's cells, diag == NULL): by default the operator's
+ * write-out and combine pass also form the v-dependent dot products of update_b (bp5/solver.h:142-311: p.v, v.v, r.v, r.r)
+ * and write the Dirichlet rows, so the separate pass over p, r, v and the copy_constrained launch disappear.  Same
+ * arithmetic, different summation order (still fixed: bitwise reproducible).  0 switches back to the separate kernels. */
+int bp5_mf_set_cg_fusion(bp5_mf *mf, int on);
+
 /* event helpers so a host in another language can time on the handle's stream */
 typedef struct bp5_event bp5_event;
 int bp5_event_create(bp5_event **out);

@@ -28,6 +28,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "bp5.h"
@@ -323,26 +324,21 @@ public:
   __device__ void submit_value(const value_type &val_in) { submit_value(val_in, index()); }
   __device__ void submit_dof_value(const value_type &val_in, const unsigned int dof) { values[dof] = val_in; }
 
+  // physical gradient at a quadrature point from the reference-space one: grad_x u = K^T ghat, K[r][c] = d xi_r / d x_c
+  // (the nine SoA planes of MatrixFree::Data; semantics of bp5/fe_evaluation_gl.h:318-343)
   __device__ gradient_type get_gradient(const unsigned int q_point) const
-  { // bp5/fe_evaluation_gl.h:318-343: grad_x = K^T ghat
-    const Number *inv_jacobian = &inv_jac[q_point];
-    gradient_type grad;
-    for (int d_1 = 0; d_1 < dim; ++d_1) {
-      Number tmp = 0.;
-      for (int d_2 = 0; d_2 < dim; ++d_2) tmp += inv_jacobian[(size_t)padding_length * n_cells * (dim * d_2 + d_1)] * gradients[d_2][q_point];
-      grad[d_1] = tmp;
-    }
-    return grad;
+  {
+    const Number gh[3] = {gradients[0][q_point], gradients[1][q_point], gradients[2][q_point]};
+    gradient_type g;
+    for (int c = 0; c < dim; ++c) g[c] = K(0, c, q_point) * gh[0] + K(1, c, q_point) * gh[1] + K(2, c, q_point) * gh[2];
+    return g;
   }
   __device__ gradient_type get_gradient() const { return get_gradient(index()); }
+  // test-function side: what integrate() contracts with is JxW K grad (semantics of bp5/fe_evaluation_gl.h:354-369)
   __device__ void submit_gradient(const gradient_type &grad_in, const unsigned int q_point)
-  { // bp5/fe_evaluation_gl.h:354-369: JxW K grad
-    const Number *inv_jacobian = &inv_jac[q_point];
-    for (int d_1 = 0; d_1 < dim; ++d_1) {
-      Number tmp = 0.;
-      for (int d_2 = 0; d_2 < dim; ++d_2) tmp += inv_jacobian[(size_t)n_cells * padding_length * (dim * d_1 + d_2)] * grad_in[d_2];
-      gradients[d_1][q_point] = tmp * JxW[q_point];
-    }
+  {
+    const Number w = JxW[q_point];
+    for (int r = 0; r < dim; ++r) gradients[r][q_point] = w * (K(r, 0, q_point) * grad_in[0] + K(r, 1, q_point) * grad_in[1] + K(r, 2, q_point) * grad_in[2]);
   }
   __device__ void submit_gradient(const gradient_type &grad_in)
   {
@@ -358,6 +354,8 @@ public:
 
 private:
   static __device__ unsigned int index() { return internal::compute_index<dim, n_q_points_1d>(); }
+  // entry (r, c) of the inverse Jacobian at this cell's quadrature point q: plane r * dim + c of inv_jacobian
+  __device__ Number K(int r, int c, unsigned int q) const { return inv_jac[(size_t)(r * dim + c) * n_cells * padding_length + q]; }
 
   // one 1-D contraction along `direction` evaluated at this thread's point; shape is dof-major
   // [i * n + q]; dof_to_quad selects shape[k * n + q] (evaluation) or shape[q * n + k] (integration)
@@ -434,12 +432,23 @@ public:
   Vector() = default;
   Vector(const Vector &) = delete;
   Vector &operator=(const Vector &) = delete;
-  ~Vector() { if (val) bp5_vec_free(val); }
+  Vector(Vector &&o) noexcept : mf(o.mf), val(o.val), n_owned(o.n_owned), n_ghost(o.n_ghost), owns(o.owns) { o.val = nullptr; }
+  ~Vector() { if (val && owns) bp5_vec_free(val); }
+  // non-owning view of n_owned + n_ghost device doubles laid out like the vectors of `handle` (the solvers hand their work
+  // vectors to a user operator's vmult(Vector &, const Vector &) this way)
+  static Vector view(bp5_mf *handle, Number *values, size_t n_owned_, size_t n_ghost_)
+  {
+    Vector v;
+    v.mf = handle; v.val = values; v.n_owned = n_owned_; v.n_ghost = n_ghost_; v.owns = false;
+    return v;
+  }
+  bp5_mf *handle() const { return mf; }
 
   // == reinit(locally_owned, ghost, comm): the index sets are those the handle was created with
   void reinit(bp5_mf *handle, size_t n_owned_, size_t n_ghost_)
   {
-    if (val) { bp5_vec_free(val); val = nullptr; }
+    if (val && owns) bp5_vec_free(val);
+    val = nullptr; owns = true;
     mf = handle; n_owned = n_owned_; n_ghost = n_ghost_;
     check(bp5_vec_alloc(n_owned + n_ghost, &val)); // zero-filled
   }
@@ -499,6 +508,14 @@ public:
     check(bp5_copy_d2h(rw.data(), val, n_owned * sizeof(Number)));
   }
   void update_ghost_values() const { check(bp5_halo_gather(mf, val)); }
+  void update_ghost_values_start() const { check(bp5_halo_gather_start(mf, val)); }
+  void update_ghost_values_finish() const { check(bp5_halo_gather_finish(mf, val)); }
+  void compress_start(VectorOperation::values op)
+  {
+    if (op != VectorOperation::add) throw std::runtime_error("Vector::compress_start: add only");
+    check(bp5_halo_scatter_add_start(mf, val));
+  }
+  void compress_finish(VectorOperation::values) { check(bp5_halo_scatter_add_finish(mf, val)); }
   void compress(VectorOperation::values op)
   {
     if (op != VectorOperation::add) throw std::runtime_error("Vector::compress: add only");
@@ -510,6 +527,7 @@ private:
   bp5_mf *mf = nullptr;
   Number *val = nullptr;
   size_t n_owned = 0, n_ghost = 0;
+  bool owns = true;
   mutable size_type n_global = 0;
 };
 } // namespace distributed
@@ -534,7 +552,16 @@ struct DiagonalMatrix { // bp5/step-64.cu:428-432; nullptr == identity
   const double *diag = nullptr;
   const double *get_vector() const { return diag; }
 };
-// A must expose  bp5_mf* handle()  and  const double* coef()  (see examples/bp5_step64.hip)
+namespace internal {
+template <typename T, typename = void> struct has_coef : std::false_type {};
+template <typename T> struct has_coef<T, decltype((void)std::declval<const T &>().coef())> : std::true_type {};
+} // namespace internal
+// cg.solve(A, x, b, preconditioner), bp5/solver.h:25-30: the solvers use nothing of A but A.vmult(dst, src).
+//  * an operator that exposes  bp5_mf* handle()  and  const double* coef()  is the library's own Poisson operator: the
+//    whole solve runs inside bp5_cg_solve (fused operator kernels, dot products inside the block kernel where possible);
+//  * ANY other MatrixType with  vmult(VectorType &dst, const VectorType &src)  (e.g. the step-64 Helmholtz operator written
+//    as a device functor, examples/bp5_step64.hip) goes through bp5_cg_solve_operator: same solver kernels, A.vmult called
+//    once per iteration on non-owning views of the solver's work vectors.
 template <int VARIANT>
 class SolverCGBase {
 public:
@@ -542,23 +569,45 @@ public:
   template <typename MatrixType>
   void solve(const MatrixType &A, double *x, const double *b, const DiagonalMatrix &preconditioner)
   {
+    static_assert(internal::has_coef<MatrixType>::value, "raw-pointer solve: the library's own operator; use the Vector overload for others");
     bp5_cg_params prm{VARIANT, (int)control.max_steps, control.tolerance, 0, 0};
     bp5_cg_result res{};
     const int s = bp5_cg_solve(A.handle(), A.coef(), preconditioner.get_vector(), b, x, &prm, &res);
-    control.lstep = res.iterations;
-    control.lvalue = res.residual;
-    result = res;
-    check(s);
+    finish(res, s);
   }
   // VectorType = LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA> (bp5/step-64.cu:450-453)
   template <typename MatrixType, typename VectorType>
   auto solve(const MatrixType &A, VectorType &x, const VectorType &b, const DiagonalMatrix &preconditioner) -> decltype((void)x.get_values())
   {
-    solve(A, x.get_values(), static_cast<const double *>(b.get_values()), preconditioner);
+    if constexpr (internal::has_coef<MatrixType>::value)
+      solve(A, x.get_values(), static_cast<const double *>(b.get_values()), preconditioner);
+    else {
+      struct Ctx { const MatrixType *A; bp5_mf *mf; size_t n_owned, n_ghost; std::string what; } ctx{&A, x.handle(), x.local_size(), x.n_ghost_entries(), {}};
+      bp5_vmult_fn tramp = [](void *c, double *dst, double *src) -> int {
+        Ctx *q = static_cast<Ctx *>(c);
+        try { // no exception may cross the C boundary
+          VectorType vd = VectorType::view(q->mf, dst, q->n_owned, q->n_ghost), vs = VectorType::view(q->mf, src, q->n_owned, q->n_ghost);
+          q->A->vmult(vd, vs);
+          return BP5_OK;
+        } catch (const std::exception &e) { q->what = e.what(); return BP5_ERR_INVALID; }
+      };
+      bp5_cg_params prm{VARIANT, (int)control.max_steps, control.tolerance, 0, 0};
+      bp5_cg_result res{};
+      const int s = bp5_cg_solve_operator(x.handle(), tramp, &ctx, preconditioner.get_vector(), static_cast<const double *>(b.get_values()), x.get_values(), &prm, &res);
+      if (s != BP5_OK && !ctx.what.empty()) throw std::runtime_error("operator vmult failed inside the solver: " + ctx.what);
+      finish(res, s);
+    }
   }
   bp5_cg_result result{};
 
 private:
+  void finish(const bp5_cg_result &res, int status)
+  {
+    control.lstep = res.iterations;
+    control.lvalue = res.residual;
+    result = res;
+    check(status);
+  }
   SolverControl &control;
 };
 using SolverCG = SolverCGBase<BP5_CG_PLAIN>;           // bp5/step-64.cu:446-453

@@ -637,6 +637,107 @@ def test_merged_cg_epilogue_parity(iters):
     assert rel(x.cpu().numpy(), xr) < TOL_CG
 
 
+@pytest.mark.parametrize("cells,block,wgs", [((9, 6, 7), (4, 4, 4), 8), ((8, 8, 5), (4, 4, 2), 16), ((4, 4, 4), (4, 4, 4), 0)])
+def test_merged_cg_with_dot_products_fused_into_the_block_kernel(cells, block, wgs):
+    """SolverCGFullMerge on the packed block kernel: the operator's write-out and combine pass also form the v-dependent dot
+    products of update_b (bp5/solver.h:142-311) and write the Dirichlet rows (copy_constrained_values, bp5/step-64.cu:275).
+    Same iteration as with the separate kernels (solution to rounding: only the summation order differs), equal to the
+    oracle's plain CG within the north-star tolerance, bitwise reproducible, and the tolerance stop fires at the same step."""
+    torch = _t()
+    p = 4
+    # (h = 1/8: on a domain of ~unit size step-64's coefficient varies by ~50; with h = 1 it varies by 6000 and CG amplifies
+    # any change of summation order to 1e-7 within 14 iterations -- fused or not)
+    mesh = pkg.BrickMesh(p, cells, h=0.125, deform_amp=0.03, cell_block=block, dof_numbering=1, cell_block_order=1)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    op.mf_data.set_apply_variant(56)
+    if wgs:
+        op.mf_data.set_block_workgroups(wgs)          # several bricks per persistent workgroup, some workgroups idle
+    assert op.mf_data.block_plan_info()[2]             # packed indices: the fused path is taken
+    pr = O.Problem(p, cells, 0, h=0.125, deform_amp=0.03, kappa=O.kappa_step64)
+    perm = mesh.global_ids.astype(np.int64)
+    b = op.assemble_rhs()
+    iters = 14
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), iters)
+    sols, ress = [], []
+    for fused in (True, False, True):
+        op.mf_data.set_cg_fusion(fused)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(iters, 0.0)
+        pkg.SolverCGFullMerge(ctl, profile=True).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == iters and ctl.apply_launches == iters
+        assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+        sols.append(x)
+        ress.append(ctl.last_value())
+    assert torch.equal(sols[0], sols[2])                                      # fixed summation order
+    assert float((sols[0] - sols[1]).abs().max()) < 1e-12 * float(sols[1].abs().max())
+    assert abs(ress[0] - ress[1]) < 1e-10 * ress[1]
+    # tolerance stop (constant coefficient, undeformed: converges in tens of iterations): the device-side convergence flag
+    # turns the fused kernels into no-ops at the same iteration, and the recurrence residual is the true one
+    op2 = pkg.PoissonOperator(pkg.BrickMesh(p, cells, h=0.125, cell_block=block, dof_numbering=1, cell_block_order=1), 0)
+    op2.mf_data.set_apply_variant(56)
+    if wgs:
+        op2.mf_data.set_block_workgroups(wgs)
+    b2 = op2.assemble_rhs()
+    bn = float(torch.linalg.norm(b2))
+    steps = []
+    for fused in (True, False):
+        op2.mf_data.set_cg_fusion(fused)
+        x = op2.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(400, 1e-8 * bn)
+        pkg.SolverCGFullMerge(ctl, check_every=7).solve(op2, x, b2, pkg.DiagonalMatrix())
+        steps.append(ctl.last_step())
+        Ax = op2.initialize_dof_vector()
+        op2.vmult(Ax, x)
+        assert float(torch.linalg.norm(Ax - b2)) < 1.0001e-8 * bn and ctl.last_value() <= 1e-8 * bn
+    assert steps[0] == steps[1] and 5 < steps[0] < 400
+    # a Jacobi-preconditioned solve keeps the separate dot-product kernel (the fused sums assume D == 1)
+    op.mf_data.set_cg_fusion(True)
+    dinv = op.compute_diagonal(invert=True)
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(iters, 0.0)
+    pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix(dinv))
+    xj, _, _ = O.cg_plain(pr.vmult, pr.rhs(), iters, diag=1.0 / O.operator_diagonal(pr.mesh, pr.coef, pr.N, pr.D))
+    assert rel(x.cpu().numpy(), xj[perm]) < TOL_CG
+
+
+@pytest.mark.parametrize("solver_name", ["SolverCG", "SolverCGFullMerge"])
+def test_solvers_take_any_operator_with_vmult(solver_name):
+    """cg.solve(A, x, b, preconditioner) needs nothing of A but A.vmult (bp5/solver.h:25-30,377,475): a foreign operator
+    (here: the library's Poisson operator plus a torch-side mass-like shift, enqueued on the same stream) is solved by the
+    same solver kernels through bp5_cg_solve_operator; iterate for iterate equal to the oracle's CG on the same operator."""
+    p, cells, sigma = 3, (4, 3, 3), 7.5
+    mesh = pkg.BrickMesh(p, cells, h=0.25, deform_amp=0.03)
+    inner = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    pr = O.Problem(p, cells, 0, h=0.25, deform_amp=0.03, kappa=O.kappa_step64)
+
+    class Shifted:
+        mf_data = inner.mf_data
+        calls = 0
+
+        def vmult(self, dst, src):
+            inner.vmult(dst, src)
+            dst.add_(src, alpha=sigma)
+            Shifted.calls += 1
+
+    b = inner.assemble_rhs()
+    its = 9
+    xr, _, _ = O.cg_plain(lambda s: pr.vmult(s) + sigma * s, pr.rhs(), its)
+    x = inner.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(its, 0.0)
+    getattr(pkg, solver_name)(ctl, profile=True).solve(Shifted(), x, b, pkg.DiagonalMatrix())
+    assert ctl.last_step() == its and Shifted.calls == its and ctl.apply_launches == its
+    assert rel(x.cpu().numpy(), xr) < TOL_CG
+
+    class Broken:
+        mf_data = inner.mf_data
+
+        def vmult(self, dst, src):
+            raise ValueError("operator failure")
+
+    with pytest.raises(ValueError):            # a failing callback aborts the solve; the error reaches the caller
+        getattr(pkg, solver_name)(pkg.IterationNumberControl(3, 0.0)).solve(Broken(), x, b, pkg.DiagonalMatrix())
+
+
 def test_p4_variable_coefficient_deformed_cg_golden():
     z = np.load(os.path.join(G, "p4_kappa_deformed_cg.npz"))
     op = pkg.PoissonOperator(pkg.BrickMesh(4, (4, 3, 3), h=0.25, deform_amp=0.04), 0, pkg.COEF_STEP64)
