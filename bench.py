@@ -33,16 +33,16 @@ def algorithmic_bytes_per_dof(p, n_cells, n_dofs, G=6, I=1, operator_only=False)
     return 16.0 + I * 4.0 * r + G * 8.0 * r + (0.0 if operator_only else 88.0)
 
 
-def measured_traffic(key):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
-    (profiles/*/traffic.json, latest round wins); None when this workload has not been profiled."""
+def measured_traffic(key, kernel):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (profiles/*/traffic.json, the latest
+    round that profiled THIS kernel build on this workload wins); None when it has not been profiled."""
     best = None
     prof = os.path.join(ROOT, "profiles")
     for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
         f = os.path.join(prof, rnd, "traffic.json")
         if os.path.exists(f):
             for e in json.load(open(f))["entries"]:
-                if e["key"] == key:
+                if e["key"] == key and e.get("kernel") == kernel:
                     best = dict(e, source=f"profiles/{rnd}/traffic.json")
     return best
 
@@ -229,11 +229,17 @@ def main():
         B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
         B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
-        achieved = B_op * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
         ev = op.mf_data.get_apply_variant()
         key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}"
-        tr = measured_traffic(key) if (args.deform == 0.0 and world == 1) else None
-        block_kernel = ev in (48, 49, 56)
+        block_kernel = ev in (48, 49, 56, 60, 61)
+        # SolverCGFullMerge on the packed block kernel, one rank: the dot products of update_b (contract: "dot reads p,r,v",
+        # 24 B/DoF of the formula's 88) are formed inside the operator's write-out (reported by the solve itself)
+        fused = bool(ctl.dot_products_fused)
+        B_kernel = B_op + (24.0 if fused else 0.0)
+        achieved = B_kernel * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
+        kname = "apply_block_kernel<4,false,32,1,1337344>" if fused else \
+            {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: "apply_block_kernel<4,false,32,1,288768>"}.get(ev, f"apply variant {ev}")
+        tr = measured_traffic(key, kname) if (args.deform == 0.0 and world == 1) else None
         out = {
             "metric": "BP5 DoFs/sec per CG iter (p=4, ~1e8 DoFs) + % HBM roofline at 1/2/4/8 GPUs",
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": iters, "warmup": args.warmup,
@@ -243,26 +249,31 @@ def main():
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world} ({args.scaling} scaling)",
-                       "cell_block": list(block) if blocked else None, "apply_variant": ev},
+                       "cell_block": list(block) if blocked else None, "apply_variant": ev, "cg_dot_products_fused": fused},
             "value_per_gpu": value / world,   # the reference's convention divides by the rank count (bp5/step-64.cu:457-461)
             "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
                             "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS,
                             "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": value / world * B / 1e9 / stream_copy_gbs},
-            # `achieved`: algorithmic bytes of ONE operator application (B_op x DoFs of this rank) / average duration of the cell
-            # kernel (HIP events on the solver's stream around that launch, inside the timed solve); `operator_ms` is the whole
-            # application: zero-fill (atomic kernels) + cell kernel + combine pass (owner-scatter kernels)
-            "roofline": {"bound": "hbm", "kernel": tr["kernel"] if tr else {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: "apply_block_kernel<4,false,32,1,288768>"}.get(ev, f"apply variant {ev}"), "achieved": achieved,
+            # `achieved`: algorithmic bytes of ONE launch of the dominant kernel / its average duration (HIP events on the solver's
+            # stream around that launch, inside the timed solve).  Unfused: one operator application, B_op x DoFs of this rank.
+            # Fused (default at p = 4 on bricks): the same kernel also does the solver's dot-product pass, so its algorithmic
+            # bytes are B_op + 24 B/DoF (the contract formula's "dot reads p, r, v"); `frac_operator_only` prices the same
+            # duration against B_op alone.  `operator_ms`: zero-fill (atomic kernels) + cell kernel + combine pass.
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["traffic_bytes"] if tr else None,
                          "traffic_source": (tr["source"] + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (not measured in this run)") if tr else None,
-                         "algorithmic_bytes": B_op * n_dofs_local,
-                         "bytes_per_dof": B_op, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
+                         "algorithmic_bytes": B_kernel * n_dofs_local,
+                         "bytes_per_dof": B_kernel, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
                          "operator_ms": ctl.operator_ms_avg,
-                         "algorithmic_formula": f"16 + I*4r + G*8r B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)",
-                         # what this kernel has to move for its own index representation (the contract formula credits I = 1)
-                         "bytes_moved_formula": (f"16 + 2r + G*8r = {16 + 2 * r + G * 8 * r:.1f} B/DoF: the block kernel reads one packed u16 (run, offset) "
-                                                 f"per cell-local DoF instead of the 4r of local_to_global") if block_kernel else
-                                                f"16 + 4r + G*8r = {B_op:.1f} B/DoF (local_to_global is read)"},
+                         "frac_operator_only": B_op * n_dofs_local / apply_s / 1e9 / HBM_PEAK_GBS if apply_s > 0 else 0.0,
+                         "algorithmic_formula": (f"16 + I*4r + G*8r" + (" + 24 [fused dot products: p, r, v]" if fused else "") +
+                                                 f" B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)"),
+                         # what this kernel has to move for its own representation (the contract formula credits I = 1 and 24 B for the dots)
+                         "bytes_moved_formula": ((f"16 + 2r + G*8r" + (" + 8 [r at the stored DoFs; p.v comes from the quadrature-point energy, v.v from LDS]" if fused else "") +
+                                                  f" = {16 + 2 * r + G * 8 * r + (8 if fused else 0):.1f} B/DoF: one packed u16 (run, offset) per cell-local DoF "
+                                                  f"instead of the 4r of local_to_global") if block_kernel else
+                                                 f"16 + 4r + G*8r = {B_op:.1f} B/DoF (local_to_global is read)")},
         }
         if sustained:
             out["sustained"] = sustained

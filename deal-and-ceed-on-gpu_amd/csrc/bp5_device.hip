@@ -97,7 +97,7 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     HIP_TRY(hipMalloc((void **)&mf->d_recvbuf, std::max<size_t>(ns, 1) * sizeof(double)));
   } else if (d->n_ghost) { return fail(BP5_ERR_INVALID, "ghosts without a halo plan"); }
   // solver workspace
-  HIP_TRY(hipMalloc((void **)&mf->d_partials, 8 * MAXBLK * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&mf->d_partials, 8 * PARTIAL_STRIDE * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&mf->d_sc, SC_COUNT * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&mf->d_scalar, 8 * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&mf->d_st, ST_COUNT * sizeof(int)));
@@ -357,8 +357,8 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
     BP5_TRY(upload(&dp.dofs, h.dofs.data(), h.dofs.size()));
     std::vector<uint32_t> run_off, runs;
     if (key < 0) {
-      // run-length form of the sorted block lists: consecutive DoFs with equal ownership flag, cut at 1024 entries so
-      // that (run, offset) packs into 6 + 10 bits
+      // run-length form of the sorted block lists: consecutive DoFs with equal ownership flag, cut at 512 entries (and where the Dirichlet flag changes) so
+      // that (run, offset) packs into 7 + 9 bits
       run_off.assign(h.off.size(), 0);
       for (size_t g = 0; g + 1 < h.off.size(); ++g) {
         uint32_t start = h.off[g];
@@ -497,7 +497,7 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
     if (mf->fuse.on) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = cg.x; cr.cg_state = mf->d_st;
-      const uint32_t grid = std::min<uint32_t>(cg.x, (uint32_t)MAXBLK - mf->fuse.n_cols);
+      const uint32_t grid = std::min<uint32_t>(cg.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols);
       hipLaunchKernelGGL((combine_runs_kernel<false, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
       mf->fuse.n_cols += grid;
@@ -550,13 +550,14 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     if (get_plan_raw(mf, -8, &dp, 64) == BP5_OK) {
       const size_t lds = ((size_t)8 * (5 * LdsLayout<5, 32>::PS + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
       mf->auto_block = lds * 3 <= 160 * 1024;
-      // persistent workgroups need enough bricks each to balance (measured: 3.6 bricks per workgroup at 54^3 cells
-      // loses 4 % against the pencil kernel, 32 per workgroup at 116^3 wins): at least 10 per workgroup
+      // persistent workgroups need enough bricks each to balance: round 1 measured 3.6 bricks per workgroup (54^3 cells)
+      // 4 % behind the pencil kernel as a bare operator; with the CG dot products fused into the write-out the block kernel
+      // is ahead there too (profiles/r2: 0.439 vs 0.446 ms per iteration), so the bar is 3 bricks per workgroup now
       if (!mf->n_cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
       }
-      if (dp->n_groups < 30u * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
+      if (dp->n_groups < 9u * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
     }
   }
   // sub-ranges: worth it only while the range still feeds the persistent grid (else the pencil kernel)
@@ -1205,6 +1206,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   HIP_TRY(hipStreamSynchronize(s)); // pinned staging words are reused below
   HIP_TRY(hipEventRecord(ev0, s));
   const bool plain = prm->variant == BP5_CG_PLAIN;
+  bool fused_dots = false;
   const int check = prm->check_every;
   int status = BP5_OK;
 
@@ -1243,7 +1245,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     hipLaunchKernelGGL(cgm_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
     // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
-    bool fused = false;
+    bool &fused = fused_dots;
     if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty()) && mf->degree == 4 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
         effective_variant(mf, 0, mf->n_cells) == 56) {
       bp5_mf::DevPlan *dp = nullptr;
@@ -1292,6 +1294,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   res->solve_ms = ms;
   res->apply_ms_avg = res->operator_ms_avg = 0.0;
   res->apply_launches = prof.used / 4;
+  res->dot_products_fused = fused_dots ? 1 : 0;
   if (prof.on && prof.used) {
     double tot = 0.0, tot_op = 0.0;
     for (int k = 0; k < prof.used; k += 4) {

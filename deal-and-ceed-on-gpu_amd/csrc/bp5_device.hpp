@@ -174,7 +174,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
   const size_t lds = ((size_t)CPT * tile_cs + ((ABL & 524288) ? 2 : 1) * (size_t)dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
-  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 64 runs per block: packed indices unavailable");
+  if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 128 runs per block: packed indices unavailable");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
   BlockPlan bp{}; // value-initialised: a field this launcher forgets is null, not garbage
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;
@@ -240,7 +240,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const dim3 grid(n_wg), block(256);
   if constexpr ((ABL & 1048576) != 0) { // fused CG dot products: whole range, overwrite mode, every DoF touched
     if (!set || atomic_shared || sub_range || mf->defer_combine || !mf->fuse.on) return fail(BP5_ERR_INVALID, "fused dot products need one whole-range overwrite launch");
-    if (n_wg > (uint32_t)MAXBLK / 2) return fail(BP5_ERR_UNSUPPORTED, "too many workgroups for the partial-sum rows");
+    if (n_wg > (uint32_t)PARTIAL_STRIDE / 2) return fail(BP5_ERR_UNSUPPORTED, "too many workgroups for the partial-sum rows");
     mf->fuse.n_cols = n_wg;
   }
   if constexpr ((ABL & 1048576) == 0) if (atomic_shared) {
@@ -550,12 +550,12 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
         bp5_mf::DevPlan *dp_ = nullptr;
         BP5_TRY(get_plan_raw(mf, -8, &dp_));
         if (variant == 60) {
-          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 60 needs packed indices (<= 64 runs per cell block)");
+          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 60 needs packed indices (<= 128 runs per cell block)");
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite);
         }
         if (variant == 61) {
-          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 61 needs packed indices (<= 64 runs per cell block)");
+          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 61 needs packed indices (<= 128 runs per cell block)");
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite);
         }

@@ -963,8 +963,8 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
 //   2048    single register set: 151-167 VGPRs -> three waves per SIMD
 //   8192    ONE transpose tile per cell, used field after field (32 lanes per cell: tile syncs are wave-local and
 //           free) -> tiles + 17^3 accumulator + run tables = 49.5 KB -> three workgroups per CU
-//   16384   run-length write-out: the brick's sorted DoF list as <= 64 runs in LDS, 16-byte stores, no list loads
-//   262144  packed indices: one u16 (run << 10 | offset) per cell-local DoF gives both the accumulator slot and the
+//   16384   run-length write-out: the brick's sorted DoF list as <= 128 runs in LDS, 16-byte stores, no list loads
+//   262144  packed indices: one u16 (run << 9 | offset) per cell-local DoF gives both the accumulator slot and the
 //           DoF to gather through that run table; local_to_global is not read
 // With the metric in the pair layout (coef_off) a lane issues 18 + 3 + 5 + 1 load instructions per cell.
 
@@ -993,9 +993,10 @@ constexpr int BLOCK_MAX_RUNS = 128;
 // run table entry "first DoF": bit 31 = the run's DoFs are touched by this block only (owner stores), bit 30 = Dirichlet DoFs
 // (builds with fused dot products write src there: copy_constrained_values folded into the write-out); DoF indices < 2^30
 constexpr uint32_t BLOCK_DOF_MASK = 0x3fffffffu, BLOCK_DOF_CONSTRAINED = 0x40000000u;
-constexpr int MAXBLK_DOTS = 2048;      // row length of the dot-product partial sums (== MAXBLK of the streaming kernels)
-constexpr int BLOCK_PACK_OFF_BITS = 10;                             // packed index = run << 10 | offset
-constexpr int BLOCK_PACK_MAX_RUNS = 1 << (16 - BLOCK_PACK_OFF_BITS); // 64
+constexpr int PARTIAL_STRIDE = 8192;   // row length of the partial-sum array d_partials[8][PARTIAL_STRIDE] (all reducing kernels)
+constexpr int BLOCK_PACK_OFF_BITS = 9;                              // packed index = run << 9 | offset (runs are cut at 512 entries)
+constexpr int BLOCK_PACK_MAX_RUNS = 1 << (16 - BLOCK_PACK_OFF_BITS); // 128 == BLOCK_MAX_RUNS
+static_assert(BLOCK_PACK_MAX_RUNS <= BLOCK_MAX_RUNS, "the LDS run table holds every packable run");
 struct BlockPlan {
   const uint32_t *pass_cell;  // [n_passes * CPT] cell id per slot; bit 31: idle slot (id still valid)
   const uint32_t *pass_off;   // [n_blocks+1] first pass of each block
@@ -1003,8 +1004,8 @@ struct BlockPlan {
   const uint32_t *dofs;       // sorted distinct DoFs per block; bit 31: touched by this block only
   const uint16_t *pos;        // [n_cells*n^3] position of each local DoF in its block's list, pair layout (coef_off(k, i + n j))
   const uint32_t *gidx;       // [n_cells*n^3] local_to_global in the same pair layout
-  // packed form (builds with ABL & 262144): ONE u16 per cell-local DoF = run << 10 | offset in the run (runs are cut at
-  // 1024 entries, at most 64 per block -- a boundary brick of a slab mesh with its ghost rows has 61); list slot = run_slot[run] + offset, DoF = run_dof[run] + offset, both from the
+  // packed form (builds with ABL & 262144): ONE u16 per cell-local DoF = run << 9 | offset in the run (runs are cut at
+  // 512 entries and where the Dirichlet flag changes, at most 128 per block -- a boundary brick of a slab mesh with its ghost rows has ~70); list slot = run_slot[run] + offset, DoF = run_dof[run] + offset, both from the
   // block's run table in LDS -- the local_to_global stream is not read at all
   const uint16_t *packed;     // [n_cells*n^3], pair layout
   const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
@@ -1021,7 +1022,7 @@ struct BlockPlan {
   unsigned long long *stamps; // diagnostic builds only: [n_wg][16] cycle sums per phase (never read by kernels)
   // builds with ABL & 1048576 (fused CG dot products, SolverCGFullMerge's update_b, bp5/solver.h:142-311): src == p, dst == v
   const double *cg_r;         // residual vector r
-  double *dot_partials;       // [7][MAXBLK] row k, column = workgroup: p.v, v.v, r.v, r.r (rows 4-6 = rows 2, 1, 3: D == 1)
+  double *dot_partials;       // [7][PARTIAL_STRIDE] row k, column = workgroup: p.v, v.v, r.v, r.r (rows 4-6 = rows 2, 1, 3: D == 1)
   uint32_t n_owned;           // dot products run over owned entries only
   const int *cg_state;        // st[ST_DONE] != 0: the solve has stopped, the launch is a no-op (iterate frozen)
 };
@@ -1141,7 +1142,7 @@ struct BlockPass {
   // one pass: compute with `cur`, keep the loads of `nxt` in flight.  Returns nothing; all
   // block bookkeeping is done by the caller.
   static __device__ __forceinline__ void run(const ApplyArgs &a, const ShapeArg<n> &sh, R &cur, R &nxt, double *T, double *acc, int a_, int b_,
-                                             int n_rounds, int abm, unsigned long long (&ph)[8], unsigned long long &tprev)
+                                             int n_rounds, int abm, unsigned long long (&ph)[8], unsigned long long &tprev, double &energy)
   {
     if constexpr (SINGLE) issue_metric(a, cur, abm);
     BP5_STAMP(0) // issue of this pass's loads
@@ -1249,6 +1250,9 @@ struct BlockPass {
           q1[i] = cur.S[3][i] * x0 + cur.S[1][i] * x1 + cur.S[5][i] * x2;
           q2[i] = cur.S[4][i] * x0 + cur.S[5][i] * x1 + cur.S[2][i] * x2;
         }
+        // fused CG: src . (A src) is the sum over cells and quadrature points of ghat^T S ghat -- everything is in
+        // registers here, the dot product costs no memory traffic at all
+        if constexpr ((ABL & 1048576) != 0) { if (act) energy += x0 * q0[i] + x1 * q1[i] + x2 * q2[i]; }
       }
       BP5_STAMP(3)
       double yy[n];
@@ -1536,13 +1540,13 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
   // DOTS: the write-out also accumulates the merged CG's v-dependent dot products over the DoFs it stores (and writes src
   // instead of the sum on Dirichlet DoFs); brick-surface DoFs are handled the same way by combine_runs_kernel<.., true>
   constexpr bool DOTS = (ABL & 1048576) != 0;
-  static_assert(!DOTS || (((ABL & 16384) != 0) && SCATTER == SC_OWNER_SET), "fused dot products: run-length write-out, overwrite mode");
+  static_assert(!DOTS || (((ABL & 16384) != 0) && ((ABL & 8192) != 0) && SCATTER == SC_OWNER_SET), "fused dot products: run-length write-out, sequential tiles, overwrite mode");
   double ds[4] = {0.0, 0.0, 0.0, 0.0};
   if constexpr (DOTS) { if (bp.cg_state[0]) return; }
   uint32_t b = bp.wg_block[w];
   const uint32_t b1 = bp.wg_block[w + 1];
   if (b >= b1) {
-    if constexpr (DOTS) { if (t < 7) bp.dot_partials[t * MAXBLK_DOTS + blockIdx.x] = 0.0; } // an idle workgroup still owns a column
+    if constexpr (DOTS) { if (t < 7) bp.dot_partials[t * PARTIAL_STRIDE + blockIdx.x] = 0.0; } // an idle workgroup still owns a column
     return;
   }
   uint32_t gp = bp.pass_off[b];
@@ -1656,19 +1660,21 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       }
     }
   };
-  auto emit = [&](int i, uint32_t g) {
+  auto emit = [&](int i, uint32_t g, double ri = 0.0) { // ri: DOTS builds, r[g] loaded ahead of the stores
     const double v = acc[i];
     acc[i] = 0.0; // re-arm for the next block (invariant: the accumulator is all zero between blocks)
     if (g & 0x80000000u) {
       const uint32_t gi = g & BLOCK_DOF_MASK;
       if constexpr (DOTS) {
-        const double pi = a.src[gi];
-        const double vi = (g & BLOCK_DOF_CONSTRAINED) ? pi : v; // copy_constrained_values (bp5/step-64.cu:275)
-        __builtin_nontemporal_store(vi, a.dst + gi);
-        if (gi < bp.n_owned) {
-          const double ri = bp.cg_r[gi];
-          ds[0] += pi * vi; ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri;
+        // p.v comes from the cells (BlockPass::run: energy); a Dirichlet row stores v = p instead of the assembled sum, which
+        // changes that product by p (p - sum)   (copy_constrained_values, bp5/step-64.cu:275)
+        double vi = v;
+        if (g & BLOCK_DOF_CONSTRAINED) {
+          vi = a.src[gi];
+          if (gi < bp.n_owned) ds[0] += vi * (vi - v);
         }
+        __builtin_nontemporal_store(vi, a.dst + gi);
+        if (gi < bp.n_owned) { ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri; }
       } else if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[gi] = v; }
       else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
         if constexpr (ABL & 65536) a.dst[gi] = v;
@@ -1677,13 +1683,13 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       else a.dst[gi] += v;
     } else {
       if constexpr (ABL & 16) { if (v == 1.2345e300) bp.partial[o0 + i] = v; }
-      else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + g, v);
+      else if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) atomic_add_f64(a.dst + (g & BLOCK_DOF_MASK), v); // (a shared run may carry the Dirichlet flag)
       else if constexpr (ABL & 65536) bp.partial[o0 + i] = v;
       else __builtin_nontemporal_store(v, bp.partial + o0 + i);
     }
   };
   // two consecutive list slots of one run: 16-byte LDS read, 16-byte global store (half the store instructions)
-  auto emit2 = [&](int i, uint32_t g) {
+  auto emit2 = [&](int i, uint32_t g, bp5_d2u rv = bp5_d2u{0.0, 0.0}) {
     const double v0 = acc[i], v1 = acc[i + 1];
     acc[i] = 0.0;
     acc[i + 1] = 0.0;
@@ -1691,17 +1697,16 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       const uint32_t gi = g & BLOCK_DOF_MASK;
       double *d = a.dst + gi;
       if constexpr (DOTS) {
-        const bp5_d2u pv = *reinterpret_cast<const bp5_d2u *>(a.src + gi);
-        const bool con = (g & BLOCK_DOF_CONSTRAINED) != 0;
-        const double w0 = con ? pv.x : v0, w1 = con ? pv.y : v1;
-        __builtin_nontemporal_store(bp5_d2u{w0, w1}, reinterpret_cast<bp5_d2u *>(d));
-        if (gi + 1 < bp.n_owned) {
-          const bp5_d2u rv = *reinterpret_cast<const bp5_d2u *>(bp.cg_r + gi);
-          ds[0] += pv.x * w0 + pv.y * w1; ds[1] += w0 * w0 + w1 * w1; ds[2] += rv.x * w0 + rv.y * w1; ds[3] += rv.x * rv.x + rv.y * rv.y;
-        } else if (gi < bp.n_owned) { // the pair straddles the end of the owned range
-          const double ri = bp.cg_r[gi];
-          ds[0] += pv.x * w0; ds[1] += w0 * w0; ds[2] += ri * w0; ds[3] += ri * ri;
+        double w0 = v0, w1 = v1;
+        if (g & BLOCK_DOF_CONSTRAINED) { // see emit(): Dirichlet rows
+          const bp5_d2u pv = *reinterpret_cast<const bp5_d2u *>(a.src + gi);
+          w0 = pv.x; w1 = pv.y;
+          if (gi < bp.n_owned) ds[0] += w0 * (w0 - v0);
+          if (gi + 1 < bp.n_owned) ds[0] += w1 * (w1 - v1);
         }
+        __builtin_nontemporal_store(bp5_d2u{w0, w1}, reinterpret_cast<bp5_d2u *>(d));
+        if (gi + 1 < bp.n_owned) { ds[1] += w0 * w0 + w1 * w1; ds[2] += rv.x * w0 + rv.y * w1; ds[3] += rv.x * rv.x + rv.y * rv.y; }
+        else if (gi < bp.n_owned) { ds[1] += w0 * w0; ds[2] += rv.x * w0; ds[3] += rv.x * rv.x; } // the pair straddles the end of the owned range
       } else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
         if constexpr (ABL & 65536) { d[0] = v0; d[1] = v1; }
         else __builtin_nontemporal_store(bp5_d2u{v0, v1}, reinterpret_cast<bp5_d2u *>(d));
@@ -1711,8 +1716,8 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
       }
     } else {
       if constexpr (SCATTER == SC_OWNER_SET_ATOMIC || SCATTER == SC_OWNER_ADD_ATOMIC) {
-        atomic_add_f64(a.dst + g, v0);
-        atomic_add_f64(a.dst + g + 1, v1);
+        atomic_add_f64(a.dst + (g & BLOCK_DOF_MASK), v0);
+        atomic_add_f64(a.dst + (g & BLOCK_DOF_MASK) + 1, v1);
       } else if constexpr (ABL & 65536) { bp.partial[o0 + i] = v0; bp.partial[o0 + i + 1] = v1; }
       else __builtin_nontemporal_store(bp5_d2u{v0, v1}, reinterpret_cast<bp5_d2u *>(bp.partial + o0 + i));
     }
@@ -1737,7 +1742,51 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
         }
       }
       __syncthreads(); // every wave has added its last contributions of this block
-      if constexpr (RUNS && !(ABL & 1)) {
+      if constexpr (DOTS) {
+        // as below, in batches of NW pairs per thread: first the run walk and ALL the batch's loads of r (they are
+        // independent: one memory latency per batch instead of one per pair), then the stores and the dot products
+        constexpr int NW = 5;
+        int r = 0;
+        for (int base = 2 * t; base < m; base += NW * 2 * TEAM) {
+          uint32_t g0[NW], g1[NW];
+          int kind[NW]; // 0 nothing, 1 pair inside one run, 2 one slot, 3 one slot + the first slot of the next run
+          bp5_d2u rv[NW];
+#pragma unroll
+          for (int j = 0; j < NW; ++j) {
+            const int i = base + j * 2 * TEAM;
+            g0[j] = g1[j] = 0u;
+            kind[j] = 0;
+            rv[j] = bp5_d2u{0.0, 0.0};
+            if (i < m) {
+              while (r + 1 < n_runs && (int)rt[r + 1] <= i) ++r;
+              g0[j] = rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]);
+              const bool run_ends = r + 1 < n_runs && (int)rt[r + 1] == i + 1;
+              const uint32_t gi = g0[j] & BLOCK_DOF_MASK; // (every DoF of a list is < n_local: the vectors hold owned + ghost entries)
+              if (i + 1 < m && !run_ends) {
+                kind[j] = 1;
+                if (g0[j] & 0x80000000u) rv[j] = *reinterpret_cast<const bp5_d2u *>(bp.cg_r + gi);
+              } else {
+                kind[j] = 2;
+                if (g0[j] & 0x80000000u) rv[j].x = bp.cg_r[gi];
+                if (i + 1 < m) {
+                  kind[j] = 3;
+                  g1[j] = rt[BLOCK_MAX_RUNS + r + 1];
+                  if (g1[j] & 0x80000000u) rv[j].y = bp.cg_r[g1[j] & BLOCK_DOF_MASK];
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NW; ++j) {
+            const int i = base + j * 2 * TEAM;
+            if (kind[j] == 1) emit2(i, g0[j], rv[j]);
+            else if (kind[j]) {
+              emit(i, g0[j], rv[j].x);
+              if (kind[j] == 3) emit(i + 1, g1[j], rv[j].y);
+            }
+          }
+        }
+      } else if constexpr (RUNS && !(ABL & 1)) {
         // thread t takes the slot pairs (2t, 2t+1) + 2 TEAM j: a pair inside one run goes out as 16 bytes
         int r = 0;
         for (int i = 2 * t; i < m; i += 2 * TEAM) {
@@ -1793,7 +1842,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     prefetch_list();
     BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entA2 = entry(gp + 2);
-    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm, ph, tprev);
+    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0]);
     finish_pass();
     BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
@@ -1802,7 +1851,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     prefetch_list();
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entB2 = entry(gp + 2);
-    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev);
+    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0]);
     finish_pass();
     BP5_STAMP(6)
     if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged); }
@@ -1822,7 +1871,7 @@ __global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(
     __syncthreads();
     if (t < 7) {
       const int k = t < 4 ? t : (t == 4 ? 2 : t == 5 ? 1 : 3); // D == 1: r.Dv = r.v, v.Dv = v.v, r.Dr = r.r
-      bp.dot_partials[t * MAXBLK_DOTS + blockIdx.x] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+      bp.dot_partials[t * PARTIAL_STRIDE + blockIdx.x] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
     }
   }
   if constexpr (ABL & 4096) {
@@ -2105,7 +2154,7 @@ struct CombineRuns {
   uint32_t n_shared;
   // DOTS builds (fused CG dot products, see apply_block_kernel): the launch is a fixed grid walking the tiles
   const double *cg_p, *cg_r;
-  double *dot_partials;    // [7][MAXBLK]; this launch writes the columns [dot_col0, dot_col0 + gridDim.x)
+  double *dot_partials;    // [7][PARTIAL_STRIDE]; this launch writes the columns [dot_col0, dot_col0 + gridDim.x)
   uint32_t dot_col0, n_owned, n_tiles;
   const int *cg_state;
 };
@@ -2141,12 +2190,15 @@ static __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr
     }
     const uint32_t g = (s_dof0[lo] & 0x7fffffffu) + j;
     if constexpr (DOTS) {
-      const double pi = cr.cg_p[g];
-      const double vi = (s_dof0[lo] & 0x80000000u) ? pi : s; // copy_constrained_values (bp5/step-64.cu:275)
+      double vi = s;
+      if (s_dof0[lo] & 0x80000000u) { // Dirichlet row: v = p (copy_constrained_values, bp5/step-64.cu:275); p.v correction as in the block kernel
+        vi = cr.cg_p[g];
+        if (g < cr.n_owned) ds[0] += vi * (vi - s);
+      }
       dst[g] = vi;
       if (g < cr.n_owned) {
         const double ri = cr.cg_r[g];
-        ds[0] += pi * vi; ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri;
+        ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri;
       }
     } else if (ADD) dst[g] += s;
     else dst[g] = s;
@@ -2163,7 +2215,7 @@ static __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr
     __syncthreads();
     if (threadIdx.x < 7) {
       const int t = threadIdx.x, k = t < 4 ? t : (t == 4 ? 2 : t == 5 ? 1 : 3); // D == 1
-      cr.dot_partials[t * MAXBLK_DOTS + cr.dot_col0 + blockIdx.x] = (s_red[k][0] + s_red[k][1]) + (s_red[k][2] + s_red[k][3]);
+      cr.dot_partials[t * PARTIAL_STRIDE + cr.dot_col0 + blockIdx.x] = (s_red[k][0] + s_red[k][1]) + (s_red[k][2] + s_red[k][3]);
     }
   }
 }
@@ -2197,7 +2249,7 @@ static __global__ void unpack_add_kernel(const uint32_t *idx, uint32_t n, const 
 }
 
 constexpr int VB = 256;      // threads per block of streaming kernels
-constexpr int MAXBLK = 2048; // grid cap; also the length of each partial-sum row
+constexpr int MAXBLK = 2048; // grid cap of the streaming kernels (<= PARTIAL_STRIDE)
 
 // mode 0: y = value ; 1: y += a x ; 2: y = a x ; 3: y = s y + a x
 template <int MODE>
@@ -2225,7 +2277,7 @@ __global__ void __launch_bounds__(VB) vec_kernel(double *y, const double *x, dou
 // block reduction of K running sums; wave64 shuffles then LDS across waves (fixed order ->
 // bitwise reproducible for a fixed grid)
 template <int K>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[K], double *partials /*[K][MAXBLK]*/)
+__device__ __forceinline__ void block_reduce_store(double (&acc)[K], double *partials /*[K][PARTIAL_STRIDE]*/)
 {
   __shared__ double red[K][VB / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2241,7 +2293,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[K], double *par
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < VB / 64; ++w) s += red[threadIdx.x][w];
-    partials[threadIdx.x * MAXBLK + blockIdx.x] = s;
+    partials[threadIdx.x * PARTIAL_STRIDE + blockIdx.x] = s;
   }
 }
 
@@ -2253,7 +2305,7 @@ __global__ void __launch_bounds__(VB) finalize_kernel(const double *partials, in
   __shared__ double red[VB];
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += VB) s += partials[k * MAXBLK + i];
+    for (int i = threadIdx.x; i < nblk; i += VB) s += partials[k * PARTIAL_STRIDE + i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = VB / 2; off > 0; off >>= 1) {

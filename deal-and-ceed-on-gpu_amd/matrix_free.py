@@ -352,6 +352,7 @@ class SolverControl:
         self._last_step, self._last_value, self._initial_value = 0, float("nan"), float("nan")
         self.solve_ms = self.apply_ms_avg = self.operator_ms_avg = 0.0
         self.apply_launches = 0
+        self.dot_products_fused = False
 
     def last_step(self):
         return self._last_step
@@ -417,6 +418,7 @@ class _SolverBase:
         c._last_step, c._last_value, c._initial_value = res.iterations, res.residual, res.initial_residual
         c.solve_ms, c.apply_ms_avg, c.apply_launches = res.solve_ms, res.apply_ms_avg, res.apply_launches
         c.operator_ms_avg = res.operator_ms_avg
+        c.dot_products_fused = bool(res.dot_products_fused)
         _lib.check(status)
         return res
 

@@ -214,8 +214,8 @@ int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
  * makes every workgroup walk several blocks even on a small mesh) */
 int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups);
 /* facts about the block kernel's plan for this handle (builds it): number of cell blocks, longest run-length list of a
- * block, and whether the packed one-u16-per-DoF index form is available (<= 64 runs per block; brick-major numbering
- * gives 23-26, a slab's boundary bricks with their ghost rows 61) -- every rank of a multi-GPU run should report 1 */
+ * block, and whether the packed one-u16-per-DoF index form is available (<= 128 runs per block; brick-major numbering
+ * gives ~30, a slab's boundary bricks with their ghost rows ~70) -- every rank of a multi-GPU run should report 1 */
 int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, int *packed_indices);
 /* the variant a whole-range application resolves to (what "0" means for this handle) */
 int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
@@ -306,6 +306,7 @@ typedef struct {
   double apply_ms_avg;     /* profile=1: average duration of one launch of the cell kernel alone  */
   int apply_launches;
   double operator_ms_avg;  /* profile=1: zero-fill + cell kernel + combine pass (one A*x without halo) */
+  int dot_products_fused;  /* 1: the solve formed its dot products inside the operator kernels (bp5_mf_set_cg_fusion) */
 } bp5_cg_result;
 
 /* == cg.solve(A, x, b, preconditioner) with DiagonalMatrix (bp5/step-64.cu:446-453,488-495).
