@@ -166,6 +166,7 @@ static bool product_variant(int degree, int v)
   if (v == 0) return true;
   if (v >= 100) return v < 200 && product_variant(degree, v - 100) && v - 100 >= 10 && v - 100 <= 14; // team kernel, atomic scatter
   if (v == 10 || v == 50 || v == 70) return true;
+  if (v == 56 && block_lpc(degree) != 0) return true;
   switch (degree) {
     case 1: case 3: return v == 1;
     case 4: return (v >= 1 && v <= 6) || (v >= 11 && v <= 14) || (v >= 48 && v <= 61) || v == 71 || v == 72;
@@ -203,7 +204,7 @@ extern "C" int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *
   if (!mf || !n_blocks || !max_runs || !packed_indices) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(mf->device));
   bp5_mf::DevPlan *dp = nullptr;
-  BP5_TRY(get_plan_raw(mf, -8, &dp, 64));
+  BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp, 64));
   *n_blocks = dp->n_groups;
   *max_runs = dp->max_runs;
   *packed_indices = dp->packed != nullptr;
@@ -532,7 +533,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 {
   const int v = mf->apply_variant;
   if (v != 0) return v;
-  if (mf->degree == 1 || mf->degree == 3) {
+  if (mf->degree == 1 || (mf->degree == 3 && mf->h_block_off.empty())) {
     if (mf->geometry_mode == BP5_GEOM_AFFINE) return 0;
     if (mf->auto_team < 0) { // an irregular cell order can exhaust the team plan's rounds: then the atomic pencil kernel
       bp5_mf::DevPlan *dp = nullptr;
@@ -540,16 +541,21 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     }
     return mf->auto_team ? 10 : 0;
   }
-  if (mf->degree != 4) return 0;
-  const int fallback = mf->geometry_mode == BP5_GEOM_AFFINE ? 10 : 0; // affine: team kernel, else pencil kernel
+  if (!block_lpc(mf->degree)) return 0;
+  const int fallback = (mf->degree == 4 && mf->geometry_mode == BP5_GEOM_AFFINE) ? 10 : mf->degree == 3 ? 10 : 0; // else the pencil kernel
+  if (mf->degree != 4 && mf->geometry_mode == BP5_GEOM_AFFINE) return 0; // the affine block build exists at p = 4 only
   uint32_t b0_, b1_;
   if (mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &b0_, &b1_)) return fallback;
   if (mf->auto_block < 0) {
     bp5_mf::DevPlan *dp = nullptr;
     mf->auto_block = 0;
-    if (get_plan_raw(mf, -8, &dp, 64) == BP5_OK) {
-      const size_t lds = ((size_t)8 * (5 * LdsLayout<5, 32>::PS + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
-      mf->auto_block = lds * 3 <= 160 * 1024;
+    if (get_plan_raw(mf, -block_cpt(mf), &dp, 64) == BP5_OK) {
+      // LDS of the default shape: one transpose tile per cell slot + the brick's accumulator + two run tables; p <= 4 must fit
+      // three workgroups per CU, p >= 5 (more registers per lane: two workgroups per CU anyway) two
+      const int n = mf->degree + 1, ps = mf->degree == 4 ? LdsLayout<5, 32>::PS : mf->degree == 6 ? LdsLayout<7, 64>::PS : mf->degree == 5 ? LdsLayout<6, 64>::PS :
+                                         mf->degree == 7 ? LdsLayout<8, 64>::PS : mf->degree == 3 ? LdsLayout<4, 16>::PS : LdsLayout<3, 16>::PS;
+      const size_t lds = ((size_t)block_cpt(mf) * (n * ps + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
+      mf->auto_block = lds * (mf->degree <= 4 ? 3 : 2) <= 160 * 1024 && (mf->degree == 4 || dp->packed);
       // persistent workgroups need enough bricks each to balance: round 1 measured 3.6 bricks per workgroup (54^3 cells)
       // 4 % behind the pencil kernel as a bare operator; with the CG dot products fused into the write-out the block kernel
       // is ahead there too (profiles/r2: 0.439 vs 0.446 ms per iteration), so the bar is 3 bricks per workgroup now
@@ -564,7 +570,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
   if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (b1_ - b0_) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return fallback;
   if (mf->auto_block && mf->geometry_mode == BP5_GEOM_AFFINE) { // the affine build needs the packed indices
     bp5_mf::DevPlan *dp = nullptr;
-    if (get_plan_raw(mf, -8, &dp, 64) != BP5_OK || !dp->packed) return fallback;
+    if (get_plan_raw(mf, -block_cpt(mf), &dp, 64) != BP5_OK || !dp->packed) return fallback;
   }
   return mf->auto_block ? 56 : fallback;
 }
@@ -968,10 +974,10 @@ static int phases_begin(bp5_mf *mf, double *dst, bool overwrite, ApplyPhases &ph
 {
   ph.user_variant = mf->apply_variant;
   const int ev = effective_variant(mf, 0, mf->n_cells);
-  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61) && mf->degree == 4;
+  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61) && block_lpc(mf->degree) != 0 && (mf->degree == 4 || ev % 100 == 56);
   ph.overwrite = false;
   if (ph.block) {
-    BP5_TRY(get_plan_raw(mf, -8, &ph.dp));
+    BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &ph.dp));
     ph.set = overwrite && ph.dp->covers_all;
     ph.overwrite = ph.set;
     if (overwrite && !ph.set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
@@ -1246,10 +1252,10 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     KERNEL_CHECK();
     // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
     bool &fused = fused_dots;
-    if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty()) && mf->degree == 4 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
+    if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty()) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
         effective_variant(mf, 0, mf->n_cells) == 56) {
       bp5_mf::DevPlan *dp = nullptr;
-      BP5_TRY(get_plan_raw(mf, -8, &dp));
+      BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));
       fused = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);
     }
     int it = 1;

@@ -120,6 +120,12 @@ struct bp5_mf {
   size_t n_local() const { return (size_t)n_owned + n_ghost; }
 };
 
+// Lanes per cell of the block-assembled kernel's default shape (one transpose tile per cell used field after field: the lanes
+// of a cell must sit in one wave, so LPC divides 64).  0 = the degree has no such shape (p = 1: x-row team kernel; p = 8: 81
+// lanes per cell do not fit a wave, atomic pencil kernel).  Cells per pass = 256 / LPC.
+constexpr int block_lpc(int degree) { return degree == 2 || degree == 3 ? 16 : degree == 4 ? 32 : degree >= 5 && degree <= 7 ? 64 : 0; }
+inline int block_cpt(const bp5_mf *mf) { return block_lpc(mf->degree) ? 256 / block_lpc(mf->degree) : 8; }
+
 template <typename T>
 inline int upload(T **dptr, const T *host, size_t count)
 {
@@ -540,6 +546,21 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
       }
       return coll ? launch_team_t<4, true, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite) : launch_team_t<4, false, 4, 25, true>(mf, coef, src, dst, c0, c1, overwrite);
     }
+    // 56 on the other degrees with a wave-local cell shape (p = 2, 3, 5, 6, 7): sequential tiles, run-length write-out, packed
+    // indices; p >= 5 keep two workgroups per CU (registers), fused CG dot products when the solver asks for them
+    if constexpr (DEG != 4 && block_lpc(DEG) != 0) if (variant == 56) {
+      constexpr int LPCB = block_lpc(DEG);
+      if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
+      struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+      bp5_mf::DevPlan *dp_ = nullptr;
+      BP5_TRY(get_plan_raw(mf, -(256 / LPCB), &dp_));
+      if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 56 needs packed indices (<= 128 runs per cell block) at this degree");
+      if (mf->fuse.on)
+        return coll ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite)
+                    : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite);
+      return coll ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
+                  : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);
+    }
     // 48 = 56 with the per-DoF CSR combine kernel instead of the run-length one (A/B)
     // 49 = 56 with run-length write-out but without packed indices (A/B)
     // 60 = 56 with the brick's src staged once in LDS (cells gather from LDS; needs the packed indices)
@@ -548,7 +569,7 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
         struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
         mf->combine_csr = variant == 48;
         bp5_mf::DevPlan *dp_ = nullptr;
-        BP5_TRY(get_plan_raw(mf, -8, &dp_));
+        BP5_TRY(get_plan_raw(mf, -8, &dp_)); // p = 4: 32 lanes per cell, 8 cells per pass
         if (variant == 60) {
           if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 60 needs packed indices (<= 128 runs per cell block)");
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite)

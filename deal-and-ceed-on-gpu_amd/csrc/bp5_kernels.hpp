@@ -127,6 +127,8 @@ template <> struct LdsLayout<5, 25> { static constexpr int RS = 5, PS = 25, CS =
 template <> struct LdsLayout<5, 32> { static constexpr int RS = 5, PS = 25, CS = 375; };
 template <> struct LdsLayout<6, 36> { static constexpr int RS = 6, PS = 36, CS = 648; };
 template <> struct LdsLayout<7, 49> { static constexpr int RS = 7, PS = 52, CS = 1092; };
+template <> struct LdsLayout<7, 64> { static constexpr int RS = 7, PS = 52, CS = 1092; };
+template <> struct LdsLayout<6, 64> { static constexpr int RS = 6, PS = 36, CS = 648; };
 template <> struct LdsLayout<8, 64> { static constexpr int RS = 9, PS = 72, CS = 1728; };
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v)
@@ -1522,7 +1524,7 @@ struct BlockPass {
 };
 
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, (ABL & 2048) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;

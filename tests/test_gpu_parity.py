@@ -321,6 +321,52 @@ def test_default_block_kernel_on_other_brick_shapes(block, cells, numbering, ord
         assert rel(c.cpu().numpy(), refc) < TOL_OP
 
 
+@pytest.mark.parametrize("p,cells,block", [(2, (9, 8, 5), (8, 8, 4)), (3, (9, 5, 6), (8, 4, 4)), (3, (5, 5, 5), (4, 4, 4)), (5, (5, 6, 3), (4, 4, 2)),
+                                           (6, (5, 4, 3), (4, 4, 2)), (6, (4, 3, 3), (4, 2, 2)), (7, (5, 3, 3), (4, 2, 2))])
+@pytest.mark.parametrize("quad", [0, 1])
+def test_deterministic_block_kernel_for_the_other_degrees(p, cells, block, quad):
+    """The non-atomic default shape (sequential tiles, run-length write-out, packed indices: variant 56) on p = 2, 3, 5, 6, 7 --
+    the reference's scatter is an FP64 atomicAdd (bp5/fe_evaluation_gl.h:176-180: non-deterministic).  Bricks with partial
+    ones at the mesh edge, several bricks per persistent workgroup, deformed cells, variable coefficient: equal to the oracle,
+    bitwise reproducible; and the merged CG with the dot products fused into it matches the oracle's plain CG."""
+    torch = _t()
+    pr = O.Problem(p, cells, quad, h=0.2, deform_amp=0.03, kappa=O.kappa_step64)
+    mesh = pkg.BrickMesh(p, cells, h=0.2, deform_amp=0.03, cell_block=block, dof_numbering=1, cell_block_order=1)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)
+    mf.set_block_workgroups(8)
+    assert mf.block_plan_info()[2]
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=61)
+    ref = pr.vmult(s)[perm]
+    outs = []
+    for _ in range(3):
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        op.vmult(d, dev(s[perm]))
+        outs.append(d)
+    assert rel(outs[0].cpu().numpy(), ref) < TOL_OP
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    acc = torch.full_like(outs[0], 0.5)                   # accumulate mode: cell_loop adds to dst
+    mf.cell_loop(op.coef, dev(s[perm]), acc)
+    refc = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)[perm]
+    assert rel(acc.cpu().numpy() - 0.5, refc) < TOL_OP
+    b = op.assemble_rhs()
+    its = 8
+    xr, _, _ = O.cg_plain(pr.vmult, pr.rhs(), its)
+    sols = []
+    for fused in (True, False):
+        mf.set_cg_fusion(fused)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(its, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.dot_products_fused == fused
+        assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+        sols.append(x)
+    assert float((sols[0] - sols[1]).abs().max()) < 1e-11 * float(sols[1].abs().max())   # (only the summation order differs)
+
+
 @pytest.mark.parametrize("quad", [0, 1])
 def test_block_kernel_on_block_aligned_cell_ranges(quad):
     """bp5_apply_cells with the block kernel on cell ranges that are unions of whole bricks (what a host that
