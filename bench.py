@@ -143,7 +143,10 @@ def main():
     # cell order / DoF numbering are the host's choice (the reference's MatrixFree::reinit reorders cells too): bricks of
     # 4x4x4 cells, parity-class order inside a brick, brick-major DoF numbering -> the library picks its block kernel
     # (p >= 5: the atomic pencil kernel gains 3-6 % from 8x8x8 parity-class bricks, profiles/r1 g_sweep_order_degrees.txt)
-    block = tuple(args.cell_block) if args.cell_block else ((4, 4, 4) if p == 4 else (8, 8, 8) if p >= 5 else (0, 0, 0))
+    # small problems (config 2's 54^3; the 116x116x14.5 slab of one of 8 ranks): 4x4x2 bricks give the persistent workgroups twice
+    # as many bricks to balance (profiles/r2: 0.427 vs 0.439 ms per iteration at 54^3)
+    small = base[0] * base[1] * base[2] // (world if strong else 1) < 400000
+    block = tuple(args.cell_block) if args.cell_block else (((4, 4, 2) if small else (4, 4, 4)) if p == 4 else (8, 8, 8) if p >= 5 else (0, 0, 0))
     blocked = all(b > 0 for b in block)
     mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world,
                          cell_block=block if blocked else (0, 0, 0), dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0)

@@ -66,7 +66,7 @@ class MFDesc(C.Structure):
                 ("n_constrained", C.c_uint32), ("n_neighbors", C.c_int), ("neighbor_rank_host", C.c_void_p),
                 ("send_offsets_host", C.c_void_p), ("send_indices_host", C.c_void_p), ("recv_offsets_host", C.c_void_p),
                 ("device", C.c_int), ("stream", C.c_void_p), ("n_cell_blocks", C.c_uint32),
-                ("cell_block_offsets_host", C.c_void_p)]
+                ("cell_block_offsets_host", C.c_void_p), ("constraint_mask_host", C.c_void_p)]
 
 
 class MFData(C.Structure):

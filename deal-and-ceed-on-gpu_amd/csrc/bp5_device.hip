@@ -82,6 +82,33 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   std::vector<double> tv;
   pack_tab(tab, tv);  BP5_TRY(upload(&mf->d_tab, tv.data(), tv.size()));
   pack_tab(tabg, tv); BP5_TRY(upload(&mf->d_tab_gauss, tv.data(), tv.size()));
+  // hanging nodes: validate the masks on the host, upload them and the two 1-D interpolation matrices
+  if (d->constraint_mask_host) {
+    std::vector<uint32_t> hm(d->constraint_mask_host, d->constraint_mask_host + d->n_cells);
+    for (uint32_t m : hm) {
+      if (!m) continue;
+      const uint32_t faces = m & 7u;
+      if (m >> 9) return fail(BP5_ERR_UNSUPPORTED, "constraint_mask: unknown bits (isolated hanging edges are not supported)");
+      if (faces != 1u && faces != 2u && faces != 4u) return fail(BP5_ERR_UNSUPPORTED, "constraint_mask: exactly one constrained face per flagged cell");
+      mf->has_hanging = true;
+    }
+    if (mf->has_hanging) {
+      BP5_TRY(upload(&mf->d_hang_mask, hm.data(), hm.size()));
+      const int n = mf->n;
+      std::vector<double> I(2 * n * n);
+      for (int h = 0; h < 2; ++h)
+        for (int a = 0; a < n; ++a) {
+          const long double x = 0.5L * tab.nodes[a] + 0.5L * h;
+          for (int b = 0; b < n; ++b) { // Lagrange polynomial of node b at x
+            long double num = 1, den = 1;
+            for (int c = 0; c < n; ++c) if (c != b) { num *= x - (long double)tab.nodes[c]; den *= (long double)tab.nodes[b] - (long double)tab.nodes[c]; }
+            I[(h * n + a) * n + b] = (double)(num / den);
+          }
+        }
+      BP5_TRY(upload(&mf->d_hang_I, I.data(), I.size()));
+      mf->apply_variant = 90;
+    }
+  }
   // halo plan
   if (d->n_neighbors > 0) {
     if (!d->neighbor_rank_host || !d->send_offsets_host || !d->recv_offsets_host) { return fail(BP5_ERR_INVALID, "halo plan arrays missing"); }
@@ -120,7 +147,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell, mf->d_hang_mask, mf->d_hang_I};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
@@ -179,6 +206,12 @@ static bool product_variant(int degree, int v)
 extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
 {
   if (!mf) return fail(BP5_ERR_INVALID, "null handle");
+  if (mf->has_hanging) {
+    if (v != 0 && v != 90) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variant 90 only");
+    mf->apply_variant = 90;
+    return BP5_OK;
+  }
+  if (v == 90) return fail(BP5_ERR_INVALID, "apply variant 90 is the hanging-node kernel: the mesh has no constraint masks");
 #ifndef BP5_TIMING_BUILDS
   if (!product_variant(mf->degree, v)) return fail(BP5_ERR_INVALID, "unknown (degree, apply variant): timing-only builds live in libbp5_timing.so");
 #endif
@@ -223,6 +256,8 @@ template <int n>
 static int launch_geometry(bp5_mf *mf, GeomOut o)
 {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 65535u * 16);
+  o.hang_mask = mf->has_hanging ? mf->d_hang_mask : nullptr;
+  o.hang_I = mf->d_hang_I;
   hipLaunchKernelGGL(geometry_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab, mf->coefficient,
                      mf->n_cells, o);
   KERNEL_CHECK();
@@ -323,7 +358,8 @@ extern "C" int bp5_mf_get_data(bp5_mf *mf, int color, bp5_mf_data *out)
     HIP_TRY(hipMemsetAsync(mf->d_JxW, 0, gp * sizeof(double), mf->stream));
     HIP_TRY(hipMemsetAsync(mf->d_qpoints, 0, 3 * gp * sizeof(double), mf->stream));
     HIP_TRY(hipMemsetAsync(mf->d_l2g_padded, 0, gp * sizeof(uint32_t), mf->stream));
-    HIP_TRY(hipMemsetAsync(mf->d_constraint_mask, 0, mf->n_cells * sizeof(uint32_t), mf->stream));
+    if (mf->has_hanging) HIP_TRY(hipMemcpyAsync(mf->d_constraint_mask, mf->d_hang_mask, mf->n_cells * sizeof(uint32_t), hipMemcpyDeviceToDevice, mf->stream));
+    else HIP_TRY(hipMemsetAsync(mf->d_constraint_mask, 0, mf->n_cells * sizeof(uint32_t), mf->stream));
     if (mf->n_cells)
       HIP_TRY(hipMemcpy2DAsync(mf->d_l2g_padded, mf->pad * sizeof(uint32_t), mf->d_l2g, mf->n3 * sizeof(uint32_t),
                                mf->n3 * sizeof(uint32_t), mf->n_cells, hipMemcpyDeviceToDevice, mf->stream));
@@ -531,6 +567,7 @@ bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uin
 // bitwise reproducible), whole cell range only; p = 4 affine geometry: team kernel; everything else: pencil kernel.
 static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 {
+  if (mf->has_hanging) return 90;
   const int v = mf->apply_variant;
   if (v != 0) return v;
   if (mf->degree == 1 || (mf->degree == 3 && mf->h_block_off.empty())) {
@@ -644,7 +681,8 @@ template <int n>
 static int launch_rhs(bp5_mf *mf, double *b)
 {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 65535u * 16);
-  hipLaunchKernelGGL(rhs_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab_gauss, mf->n_cells, b);
+  hipLaunchKernelGGL(rhs_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab_gauss, mf->n_cells, b,
+                     mf->has_hanging ? (const uint32_t *)mf->d_hang_mask : (const uint32_t *)nullptr, (const double *)mf->d_hang_I);
   KERNEL_CHECK();
   return BP5_OK;
 }
@@ -673,6 +711,7 @@ extern "C" int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag
 {
   if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !diag) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(mf->device));
+  if (mf->has_hanging) return fail(BP5_ERR_UNSUPPORTED, "bp5_compute_diagonal on meshes with hanging nodes");
   HIP_TRY(hipMemsetAsync(diag, 0, mf->n_local() * sizeof(double), mf->stream));
   if (mf->n_cells) BP5_TRY(diagonal_dispatch(mf, coef, diag));
   if (mf->comm && !mf->neighbors.empty()) { // ghost contributions to their owners
@@ -691,7 +730,7 @@ static int launch_l2(bp5_mf *mf, const double *u, double *out)
 {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 4096u);
   hipLaunchKernelGGL(l2norm_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, mf->d_coords, mf->d_tab_gauss, mf->n_cells, u,
-                     out);
+                     out, mf->has_hanging ? (const uint32_t *)mf->d_hang_mask : (const uint32_t *)nullptr, (const double *)mf->d_hang_I);
   KERNEL_CHECK();
   return BP5_OK;
 }

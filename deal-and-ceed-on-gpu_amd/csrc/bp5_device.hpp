@@ -65,6 +65,10 @@ struct bp5_mf {
   double *d_coords = nullptr, *d_tab = nullptr, *d_tab_gauss = nullptr;
   // Data mirror (lazy)
   uint32_t *d_l2g_padded = nullptr, *d_constraint_mask = nullptr;
+  // hanging nodes (2:1 refinement): per-cell masks and the two 1-D interpolation matrices [2][n*n]; has_hanging: some mask != 0
+  bool has_hanging = false;
+  uint32_t *d_hang_mask = nullptr;
+  double *d_hang_I = nullptr;
   double *d_inv_jac = nullptr, *d_JxW = nullptr, *d_qpoints = nullptr;
   uint32_t pad = 0;
   // halo plan
@@ -155,6 +159,8 @@ inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
   a.cell_begin = c0; a.cell_end = c1;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  a.hang_mask = mf->d_hang_mask; a.hang_I = mf->d_hang_I;
+  if ((ABL & 2097152) && !mf->has_hanging) return fail(BP5_ERR_INVALID, "the hanging-node build needs constraint masks");
   a.n_teams = (c1 - c0 + CPT - 1) / CPT;
   const uint32_t nblk = (a.n_teams + TPB - 1) / TPB;
   a.teams_per_xcd = (nblk + 7) / 8;
@@ -394,6 +400,18 @@ inline int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0
 template <int DEG>
 int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
 {
+  if (mf->has_hanging) {
+    // 2:1 refined meshes: the degree's default pencil shape with the hanging-node fix-up after the gather and its adjoint
+    // before the (atomic) scatter -- variant 90, the only operator kernel that honours constraint masks
+    if (mf->apply_variant != 90) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variant 90 only");
+    if (mf->geometry_mode == BP5_GEOM_AFFINE) return fail(BP5_ERR_UNSUPPORTED, "hanging nodes with the affine geometry mode");
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    if (c1 <= c0) return BP5_OK;
+    constexpr int n2h = (DEG + 1) * (DEG + 1);
+    constexpr int TWH = DEG <= 3 ? 1 : 4, TPBH = DEG <= 3 ? 4 : 1;
+    return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<DEG, true, TWH, n2h, TPBH, true, 2097152>(mf, coef, src, dst, c0, c1)
+                                          : launch_apply_t<DEG, false, TWH, n2h, TPBH, true, 2097152>(mf, coef, src, dst, c0, c1);
+  }
   if (mf->geometry_mode == BP5_GEOM_AFFINE && c1 > c0) {
     const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
     const bool whole = c0 == 0 && c1 == mf->n_cells;

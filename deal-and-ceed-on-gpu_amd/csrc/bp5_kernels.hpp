@@ -71,6 +71,26 @@ struct ApplyArgs {
   uint32_t teams_per_xcd;
   const double *gcell;   // affine mode: [6][n_cells] per-cell K K^T (planes 00,11,22,01,02,12); coef = 1 scalar plane
   uint32_t n_cells_total;
+  // hanging nodes (builds with ABL & 2097152): per-cell constraint mask (bp5.h BP5_HANG_*) and the two 1-D interpolation
+  // matrices I[h][a][b] = phi_b(xi_a / 2 + h / 2)
+  const uint32_t *hang_mask;
+  const double *hang_I;
+};
+
+// constraint-mask decoding shared by every kernel that gathers or scatters through local_to_global (bp5.h: BP5_HANG_*):
+// bits 0-2 constrained face normal to x / y / z (one per cell), bits 3-5 that face sits at xi = 1, bits 6-8 the fine cell covers
+// the upper half of the coarse cell along x / y / z (used for the two directions tangential to the face)
+struct HangFace {
+  int d, side, t1, t2, h1, h2;
+  __device__ __forceinline__ explicit HangFace(uint32_t m)
+  {
+    d = (m & 1u) ? 0 : (m & 2u) ? 1 : 2;
+    side = (m >> (3 + d)) & 1u;
+    t1 = d == 0 ? 1 : 0;
+    t2 = d == 2 ? 1 : 2;
+    h1 = (m >> (6 + t1)) & 1u;
+    h2 = (m >> (6 + t2)) & 1u;
+  }
 };
 
 // In-register n x n mat-vec with wave-uniform matrix entries.  The 1-D tables are symmetric
@@ -137,6 +157,45 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v)
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Hanging-node fix-up of one cell's local vector in the pencil layout (lane (a_, b_) = (i, j) holds k = 0..n-1 in registers):
+// the entries on the constrained face hold the COARSE face's DoF values and become the fine face's nodal values (TR: the adjoint,
+// applied to the cell's result before the scatter) -- resolve_hanging_nodes at bp5/fe_evaluation_gl.h:150-151,167-168.  Every lane
+// of the team runs the exchange (team-wide syncs), only flagged cells change values.  T: the cell's first LDS tile.
+template <int n, int TW, bool TR, typename L>
+__device__ __forceinline__ void pencil_hang_resolve(uint32_t m, const double *__restrict__ I, double (&u)[n], double *T, int a_, int b_, bool active)
+{
+  const HangFace f(m & 0x1ffu);
+  const bool on = active && (m & 7u) != 0;
+#define TH(k, j, i) T[(k) * L::PS + (j) * L::RS + (i)]
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    const int t = sweep == 0 ? f.t1 : f.t2;
+    const double *M = I + (sweep == 0 ? f.h1 : f.h2) * n * n;
+    team_sync<TW>();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) TH(k, b_, a_) = u[k];
+    }
+    team_sync<TW>();
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) {
+        const int idx[3] = {a_, b_, k};
+        if (idx[f.d] != f.side * (n - 1)) continue;
+        double acc = 0.0;
+        for (int q = 0; q < n; ++q) {
+          int e[3] = {a_, b_, k};
+          e[t] = q;
+          const double w = TR ? M[q * n + idx[t]] : M[idx[t] * n + q];
+          acc += w * TH(e[2], e[1], e[0]);
+        }
+        u[k] = acc;
+      }
+    }
+  }
+  team_sync<TW>();
+#undef TH
+}
+
 // ------------------------------------------------------------------------------------ fused operator
 // P degree, COLL: quadrature == GLL (N == I), TW waves per team, LPC lanes per cell slot,
 // TPB teams per block (TW > 1 requires TPB == 1), PF: prefetch all six planes before evaluate
@@ -180,6 +239,11 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
   for (int k = 0; k < n; ++k) idx[k] = (ABL & 256) ? __builtin_nontemporal_load(l2g_c + k * n2) : l2g_c[k * n2];
 #pragma unroll
   for (int k = 0; k < n; ++k) u[k] = (ABL & 4) ? 1e-9 * idx[k] : a.src[idx[k]];
+  uint32_t hmask = 0;
+  if constexpr ((ABL & 2097152) != 0) { // hanging nodes: coarse-face values -> this cell's own face nodes
+    hmask = a.hang_mask[cell];
+    pencil_hang_resolve<n, TW, false, L>(hmask, a.hang_I, u, T, a_, b_, active);
+  }
 
   if constexpr (ABL & 131072) { // timing only: the E-vector-sized write stream issued at the START of the workgroup
     if (active) {
@@ -359,6 +423,7 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     MV_DT_ADD(sh.D, z2, y);
   }
 
+  if constexpr ((ABL & 2097152) != 0) pencil_hang_resolve<n, TW, true, L>(hmask, a.hang_I, y, T, a_, b_, active); // adjoint, before the scatter
   // ---- scatter-add (distribute_local_to_global, bp5/fe_evaluation_gl.h:170-180)
   if constexpr (ABL & 1) {
     double acc = 0.0;
@@ -1911,6 +1976,33 @@ struct Cell3 {
   }
 };
 
+// hanging-node fix-up in the generic layout (one thread per (i,j,k), v in LDS); the whole block calls it
+template <int n, bool TR>
+__device__ void hang_resolve3(uint32_t m, const double *I, double *v, double *t, int i, int j, int k)
+{
+  if (!(m & 7u)) return; // block-uniform
+  const HangFace f(m & 0x1ffu);
+  const int idx[3] = {i, j, k}, q = i + n * (j + n * k);
+  const bool on = idx[f.d] == f.side * (n - 1);
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    const int td = sweep == 0 ? f.t1 : f.t2;
+    const double *M = I + (sweep == 0 ? f.h1 : f.h2) * n * n;
+    double acc = v[q];
+    if (on) {
+      acc = 0.0;
+      for (int r = 0; r < n; ++r) {
+        int e[3] = {i, j, k};
+        e[td] = r;
+        acc += (TR ? M[r * n + idx[td]] : M[idx[td] * n + r]) * v[e[0] + n * (e[1] + n * e[2])];
+      }
+    }
+    t[q] = acc;
+    __syncthreads();
+    v[q] = t[q];
+    __syncthreads();
+  }
+}
+
 struct GeomOut {
   double *coef;          // permuted merged metric or NULL
   uint64_t plane_stride; // n_cells * n3
@@ -1923,6 +2015,8 @@ struct GeomOut {
   // per-cell deviation measure max_q |K K^T(q) - K K^T(q0)| / |K K^T(q0)|
   double *scalar, *gcell, *deviation;
   uint32_t n_cells;
+  const uint32_t *hang_mask; // NULL: conforming mesh
+  const double *hang_I;
 };
 
 __device__ __forceinline__ double kappa_eval(int mode, double x, double y, double z)
@@ -1971,6 +2065,8 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
     const uint32_t g = l2g[cell * n3 + q];
     for (int e = 0; e < 3; ++e) X[e * n3 + q] = coords[3 * (uint64_t)g + e];
     __syncthreads();
+    if (o.hang_mask) // the coordinate field is an FE function: the constrained face takes its nodes from the coarse face's
+      for (int e = 0; e < 3; ++e) hang_resolve3<n, false>(o.hang_mask[cell], o.hang_I, X + e * n3, t1, i, j, k);
     double J[3][3], K[3][3], xq[3];
     cell_jacobian<n>(tab, X, t1, t2, i, j, k, J, xq);
     const double det = invert3(J, K);
@@ -2034,7 +2130,7 @@ __global__ void metric_permute_kernel(const double *in, double *out, uint64_t to
 // b_i = sum_q phi_i(x_q) JxW(q), Gauss tables (assemble_rhs, bp5/step-64.cu:372-418)
 template <int n>
 __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const double *coords, const double *tab_gauss,
-                                                     uint32_t n_cells, double *b)
+                                                     uint32_t n_cells, double *b, const uint32_t *hang_mask, const double *hang_I)
 {
   constexpr int n2 = n * n, n3 = n2 * n;
   __shared__ double X[3 * n3], t1[n3], t2[n3], v[n3];
@@ -2044,6 +2140,8 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
     const uint32_t g = l2g[cell * n3 + q];
     for (int e = 0; e < 3; ++e) X[e * n3 + q] = coords[3 * (uint64_t)g + e];
     __syncthreads();
+    const uint32_t hm = hang_mask ? hang_mask[cell] : 0u;
+    for (int e = 0; e < 3; ++e) hang_resolve3<n, false>(hm, hang_I, X + e * n3, t1, i, j, k);
     double J[3][3], K[3][3], xq[3];
     cell_jacobian<n>(tab_gauss, X, t1, t2, i, j, k, J, xq);
     const double det = invert3(J, K);
@@ -2051,7 +2149,13 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
     v[q] = fabs(det) * w[i] * w[j] * w[k];
     __syncthreads();
     const double *N = tab_gauss;
-    const double y = Cell3<n>::template tensor3<true>(N, N, N, v, t1, t2, i, j, k);
+    double y = Cell3<n>::template tensor3<true>(N, N, N, v, t1, t2, i, j, k);
+    if (hm & 7u) { // adjoint of the hanging-node interpolation before the scatter
+      v[q] = y;
+      __syncthreads();
+      hang_resolve3<n, true>(hm, hang_I, v, t1, i, j, k);
+      y = v[q];
+    }
     atomic_add_f64(b + g, y);
     __syncthreads();
   }
@@ -2101,7 +2205,8 @@ static __global__ void reciprocal_kernel(double *v, size_t n)
 // sum_cells sum_q (u_h(x_q))^2 JxW  -> *out (atomic)
 template <int n>
 __global__ void __launch_bounds__(n *n *n) l2norm_kernel(const uint32_t *l2g, const double *coords, const double *tab_gauss,
-                                                        uint32_t n_cells, const double *u, double *out)
+                                                        uint32_t n_cells, const double *u, double *out, const uint32_t *hang_mask,
+                                                        const double *hang_I)
 {
   constexpr int n2 = n * n, n3 = n2 * n;
   __shared__ double X[3 * n3], t1[n3], t2[n3], v[n3];
@@ -2113,6 +2218,11 @@ __global__ void __launch_bounds__(n *n *n) l2norm_kernel(const uint32_t *l2g, co
     for (int e = 0; e < 3; ++e) X[e * n3 + q] = coords[3 * (uint64_t)g + e];
     v[q] = u[g];
     __syncthreads();
+    if (hang_mask) {
+      const uint32_t hm = hang_mask[cell];
+      for (int e = 0; e < 3; ++e) hang_resolve3<n, false>(hm, hang_I, X + e * n3, t1, i, j, k);
+      hang_resolve3<n, false>(hm, hang_I, v, t1, i, j, k);
+    }
     double J[3][3], K[3][3], xq[3];
     cell_jacobian<n>(tab_gauss, X, t1, t2, i, j, k, J, xq);
     const double det = invert3(J, K);

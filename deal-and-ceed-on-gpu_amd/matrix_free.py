@@ -98,6 +98,10 @@ class MatrixFree:
         if blocks is not None:
             keep.append(np.ascontiguousarray(blocks, dtype=np.uint32))
             d.n_cell_blocks, d.cell_block_offsets_host = keep[-1].size - 1, keep[-1].ctypes.data
+        cmask = getattr(mesh, "constraint_mask", None)      # hanging-node masks of 2:1 refined meshes (BP5_HANG_* bits)
+        if cmask is not None:
+            keep.append(np.ascontiguousarray(cmask, dtype=np.uint32))
+            d.constraint_mask_host = keep[-1].ctypes.data
         h = C.c_void_p()
         _lib.check(L.bp5_mf_create(C.byref(d), C.byref(h)))
         self._h = h

@@ -5,6 +5,8 @@
 //
 //   bp5_step64 check <degree> <nx> <ny> <nz> <deform> <prefix>   functor path vs fused path; dumps vectors
 //   bp5_step64 bench <degree> <n> <iterations> <repetitions>     prints pcg-standard / pcg-merged / vmult lines
+//   bp5_step64 hanging <degree> <prefix>                         externally generated 2:1 refined mesh (<prefix>_l2g/_coords/_constrained/
+//                                                                _mask/_src.bin): functor path with resolve_hanging_nodes vs library kernel
 //   bp5_step64 helmholtz <degree> <n> <prefix>                   HelmholtzProblem::solve of step-64/step-64.cu on n^3 cells of the
 //                                                                unit cube: the functor operator inside the library's CG solvers
 #include <cmath>
@@ -144,7 +146,8 @@ using DeviceVector = LinearAlgebra::distributed::Vector<double, MemorySpace::CUD
 template <int dim, int fe_degree>
 class PoissonOperator {
 public:
-  PoissonOperator(const bp5_mesh_view &mv, int quadrature, bool use_functor_path) : functor_path(use_functor_path), do_zero_out(true)
+  PoissonOperator(const bp5_mesh_view &mv, int quadrature, bool use_functor_path, const uint32_t *constraint_mask_host = nullptr)
+    : functor_path(use_functor_path), do_zero_out(true)
   {
     bp5_mf_desc d{};
     d.dim = dim; d.degree = fe_degree; d.quadrature = quadrature; d.coefficient = BP5_COEF_ONE;
@@ -152,6 +155,7 @@ public:
     d.local_to_global_host = mv.local_to_global_host; d.node_coords_host = mv.node_coords_host;
     d.constrained_host = mv.constrained_host; d.n_constrained = mv.n_constrained;
     d.n_cell_blocks = mv.n_cell_blocks; d.cell_block_offsets_host = mv.cell_block_offsets_host; // cells handed over in bricks (if any)
+    d.constraint_mask_host = constraint_mask_host; // hanging nodes of a 2:1 refined mesh (BP5_HANG_* bits), or NULL
     mf_data.reinit(d);
     n_owned_cells = mv.n_cells;
     n_local = mv.n_owned + mv.n_ghost;
@@ -431,6 +435,52 @@ static int run_helmholtz(uint32_t ncell, const std::string &prefix)
   return 0;
 }
 
+template <typename T>
+static std::vector<T> slurp(const std::string &path)
+{
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot read " + path);
+  fseek(f, 0, SEEK_END);
+  const long bytes = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<T> v(bytes / sizeof(T));
+  if (fread(v.data(), sizeof(T), v.size(), f) != v.size()) { fclose(f); throw std::runtime_error("short read: " + path); }
+  fclose(f);
+  return v;
+}
+// A mesh with hanging nodes handed over as flat arrays (what a host sitting under real deal.II would extract): the user functor
+// goes through FEEvaluation::read_dof_values / distribute_local_to_global, which resolve the hanging-node constraints from
+// Data::constraint_mask (bp5/fe_evaluation_gl.h:150-151,167-168); the library's own kernel (apply variant 90) does the same.
+template <int fe_degree>
+static int run_hanging(const std::string &prefix)
+{
+  constexpr int dim = 3, n3 = (fe_degree + 1) * (fe_degree + 1) * (fe_degree + 1);
+  const auto l2g = slurp<uint32_t>(prefix + "_l2g.bin"), constrained = slurp<uint32_t>(prefix + "_constrained.bin"), mask = slurp<uint32_t>(prefix + "_mask.bin");
+  const auto coords = slurp<double>(prefix + "_coords.bin"), s = slurp<double>(prefix + "_src.bin");
+  bp5_mesh_view mv{};
+  mv.degree = fe_degree; mv.n_cells = (uint32_t)(l2g.size() / n3); mv.n_interior_cells = mv.n_cells;
+  mv.n_owned = (uint32_t)(coords.size() / 3); mv.n_ghost = 0; mv.n_global_dofs = mv.n_owned;
+  mv.local_to_global_host = l2g.data(); mv.node_coords_host = coords.data();
+  mv.constrained_host = constrained.data(); mv.n_constrained = (uint32_t)constrained.size();
+  if (mask.size() != mv.n_cells || s.size() != mv.n_owned) throw std::runtime_error("hanging: array sizes do not match");
+  PoissonOperator<dim, fe_degree> fast(mv, BP5_QUAD_GAUSS, false, mask.data()), generic(mv, BP5_QUAD_GAUSS, true, mask.data());
+  const size_t n = mv.n_owned;
+  double *src, *d1, *d2, *d3;
+  fast.initialize_dof_vector(&src); fast.initialize_dof_vector(&d1); fast.initialize_dof_vector(&d2); fast.initialize_dof_vector(&d3);
+  check(bp5_copy_h2d(src, s.data(), n * sizeof(double)));
+  fast.vmult(d1, src);
+  generic.vmult(d2, src);
+  generic.vmult_unmerged(d3, src);
+  check(bp5_mf_sync(fast.handle()));
+  check(bp5_mf_sync(generic.handle()));
+  const auto h1 = download(d1, n), h2 = download(d2, n), h3 = download(d3, n);
+  printf("hanging p=%d cells=%u dofs=%zu\nfunctor_vs_library %.3e\nunmerged_functor_vs_library %.3e\n", fe_degree, mv.n_cells, n, rel_diff(h2, h1), rel_diff(h3, h1));
+  dump(prefix + "_out_library.bin", h1);
+  dump(prefix + "_out_functor.bin", h2);
+  dump(prefix + "_out_functor_unmerged.bin", h3);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   try {
@@ -442,6 +492,11 @@ int main(int argc, char **argv)
         case 2: return run_check<2>(nx, ny, nz, deform, argv[7]);
         case 3: return run_check<3>(nx, ny, nz, deform, argv[7]);
         case 4: return run_check<4>(nx, ny, nz, deform, argv[7]);
+      }
+    } else if (argc >= 4 && !strcmp(argv[1], "hanging")) {
+      switch (atoi(argv[2])) {
+        case 2: return run_hanging<2>(argv[3]);
+        case 3: return run_hanging<3>(argv[3]);
       }
     } else if (argc >= 5 && !strcmp(argv[1], "helmholtz")) {
       switch (atoi(argv[2])) {

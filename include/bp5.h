@@ -35,7 +35,7 @@ enum {
   BP5_ERR_HIP = 2,            /* a HIP runtime call failed (AssertCuda, bp5/solver.h:396-397)  */
   BP5_ERR_NO_DEVICE = 3,      /* no gfx950 device visible: there is NO CPU fallback            */
   BP5_ERR_RCCL = 4,           /* an RCCL call failed                                           */
-  BP5_ERR_UNSUPPORTED = 5,    /* e.g. hanging-node constraint mask != 0                        */
+  BP5_ERR_UNSUPPORTED = 5,    /* e.g. isolated hanging edges, two constrained faces on one cell */
   BP5_ERR_BREAKDOWN = 6,      /* CG breakdown: p.Ap == 0 or NaN (ExcDivideByZero, solver.h:501)*/
   BP5_ERR_NO_CONVERGENCE = 7  /* SolverControl::NoConvergence, bp5/solver.h:539-540            */
 };
@@ -144,7 +144,24 @@ typedef struct {
    * the fewest DoFs shared between groups); NULL = the library groups 64 consecutive cells      */
   uint32_t n_cell_blocks;
   const uint32_t *cell_block_offsets_host; /* [n_cell_blocks+1], first 0, last n_cells           */
+  /* optional: hanging-node constraints of 2:1 refined meshes, one mask per cell (BP5_HANG_* below); NULL = conforming mesh.
+   * == MatrixFree::Data::constraint_mask as consumed by resolve_hanging_nodes, bp5/fe_evaluation_gl.h:150-151,167-168 */
+  const uint32_t *constraint_mask_host;   /* [n_cells]                                          */
 } bp5_mf_desc;
+
+/* constraint_mask bits.  A fine cell one of whose faces lies on a coarser neighbour ("hanging" face; planar 2:1 interfaces:
+ * at most one such face per cell, isolated hanging edges are refused with BP5_ERR_UNSUPPORTED):
+ *   BP5_HANG_FACE_d   the face normal to direction d is constrained;
+ *   BP5_HANG_SIDE_d   ... and it is the face at xi_d = 1 (else xi_d = 0);
+ *   BP5_HANG_HALF_t   for the two directions t tangential to that face: the fine face covers the upper half [1/2, 1] of the
+ *                     coarse face along t (else the lower half).
+ * local_to_global of the (p+1)^2 entries ON that face names the COARSE face's DoFs in the same orientation.  Gathers
+ * (read_dof_values, and the node coordinates of the geometry) interpolate them to the fine face's nodes with the two 1-D
+ * matrices I_h[a][b] = phi_b(xi_a / 2 + h / 2); scatters (distribute_local_to_global, RHS assembly) apply the adjoint.
+ * (deal.II's own bit layout is not part of the reference repository; this one is the library's.) */
+enum { BP5_HANG_FACE_X = 1, BP5_HANG_FACE_Y = 2, BP5_HANG_FACE_Z = 4,
+       BP5_HANG_SIDE_X = 8, BP5_HANG_SIDE_Y = 16, BP5_HANG_SIDE_Z = 32,
+       BP5_HANG_HALF_X = 64, BP5_HANG_HALF_Y = 128, BP5_HANG_HALF_Z = 256 };
 
 /* == MatrixFree::reinit(mapping, dof_handler, constraints, quad, additional_data),
  *    bp5/step-64.cu:234-248.  Uploads the flat arrays; computes nothing yet. */
@@ -185,7 +202,7 @@ typedef struct {
   const double *inv_jacobian;      /* [9][n_cells*padding_length], plane d*3+e = d xi_d/d x_e   */
   const double *JxW;               /* [n_cells*padding_length]                                  */
   const double *q_points;          /* [3][n_cells*padding_length]                               */
-  const uint32_t *constraint_mask; /* [n_cells], all zero (conforming meshes only)              */
+  const uint32_t *constraint_mask; /* [n_cells], BP5_HANG_* bits (all zero on conforming meshes) */
   uint32_t n_cells, padding_length, row_start;
   int use_coloring;
 } bp5_mf_data;

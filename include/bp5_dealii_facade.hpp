@@ -64,6 +64,41 @@ constexpr int max_n1d = BP5_MAX_DEGREE + 1;
 // 1-D tables, dof-major like deal.II's global_shape_values: [i * n_q + q]
 static __constant__ double global_shape_values[max_n1d * max_n1d];
 static __constant__ double global_shape_gradients[max_n1d * max_n1d];
+// hanging nodes: I[h][a][b] = phi_b(xi_a / 2 + h / 2), the coarse 1-D basis at the nodes of the lower / upper half
+static __constant__ double global_hanging_interpolation[2 * max_n1d * max_n1d];
+
+namespace internal {
+// resolve_hanging_nodes<dim, fe_degree, transpose>(constraint_mask, values) -- the call of bp5/fe_evaluation_gl.h:150-151,167-168
+// (upstream code in deal.II); mask bits: bp5.h BP5_HANG_*.  One thread per local DoF, `values` in shared memory, whole block calls.
+template <int dim, int fe_degree, bool transpose, typename Number>
+__device__ inline void resolve_hanging_nodes(const unsigned int constraint_mask, Number *values)
+{
+  static_assert(dim == 3, "dim == 3");
+  if (!(constraint_mask & 7u)) return; // block-uniform
+  constexpr int n = fe_degree + 1;
+  const int d = (constraint_mask & BP5_HANG_FACE_X) ? 0 : (constraint_mask & BP5_HANG_FACE_Y) ? 1 : 2;
+  const int side = (constraint_mask >> (3 + d)) & 1u;
+  const int idx[3] = {(int)(threadIdx.x % n), (int)threadIdx.y, (int)threadIdx.z};
+  const int q = idx[0] + n * (idx[1] + n * idx[2]);
+  const bool on = idx[d] == side * (n - 1);
+  for (int t = 0; t < 3; ++t) { // the two directions tangential to the face, one sweep each
+    if (t == d) continue;
+    const double *M = global_hanging_interpolation + ((constraint_mask >> (6 + t)) & 1u) * n * n;
+    Number acc = values[q];
+    if (on) {
+      acc = 0;
+      for (int r = 0; r < n; ++r) {
+        int e[3] = {idx[0], idx[1], idx[2]};
+        e[t] = r;
+        acc += (transpose ? M[r * n + idx[t]] : M[idx[t] * n + r]) * values[e[0] + n * (e[1] + n * e[2])];
+      }
+    }
+    __syncthreads();
+    values[q] = acc;
+    __syncthreads();
+  }
+}
+} // namespace internal
 
 template <int dim, typename Number>
 struct SharedData { // [upstream] C5
@@ -129,6 +164,20 @@ public:
     if (hipMemcpyToSymbol(HIP_SYMBOL(global_shape_values), sv.data(), n * n * sizeof(double)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(global_shape_gradients), sg.data(), n * n * sizeof(double)) != hipSuccess)
       throw std::runtime_error("hipMemcpyToSymbol failed");
+    { // hanging-node interpolation matrices from the FE_Q nodes
+      std::vector<double> nodes(n), I(2 * n * n);
+      check(bp5_shape_tables(degree, desc.quadrature, nodes.data(), nullptr, nullptr, nullptr, nullptr));
+      for (int h = 0; h < 2; ++h)
+        for (int a = 0; a < n; ++a)
+          for (int b = 0; b < n; ++b) {
+            long double num = 1, den = 1;
+            const long double x = 0.5L * nodes[a] + 0.5L * h;
+            for (int c = 0; c < n; ++c) if (c != b) { num *= x - (long double)nodes[c]; den *= (long double)nodes[b] - (long double)nodes[c]; }
+            I[(h * n + a) * n + b] = (double)(num / den);
+          }
+      if (hipMemcpyToSymbol(HIP_SYMBOL(global_hanging_interpolation), I.data(), 2 * n * n * sizeof(double)) != hipSuccess)
+        throw std::runtime_error("hipMemcpyToSymbol failed");
+    }
     bp5_mf_data d;
     check(bp5_mf_get_data(mf, 0, &d));
     data.q_points = const_cast<Number *>(d.q_points);
@@ -265,10 +314,11 @@ public:
     const unsigned int idx = internal::compute_index<dim, n_q_points_1d>();
     values[idx] = src[local_to_global[idx]];
     __syncthreads();
-    // constraint_mask == 0 on conforming meshes: no hanging-node resolution
+    internal::resolve_hanging_nodes<dim, fe_degree, false>(constraint_mask, values);
   }
   __device__ void distribute_local_to_global(Number *dst) const
   { // bp5/fe_evaluation_gl.h:156-181
+    internal::resolve_hanging_nodes<dim, fe_degree, true>(constraint_mask, values);
     const unsigned int idx = internal::compute_index<dim, n_q_points_1d>();
     if (use_coloring) dst[local_to_global[idx]] += values[idx];
     else __hip_atomic_fetch_add(dst + local_to_global[idx], values[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

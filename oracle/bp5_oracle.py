@@ -173,6 +173,148 @@ class BrickMesh:
         self.constrained = np.sort(g.ravel()).astype(np.uint32)
 
 
+# ----------------------------------------------------------------------------- hanging nodes (2:1 refinement)
+# constraint_mask bits of a cell (include/bp5.h BP5_HANG_*; role of MatrixFree::Data::constraint_mask consumed by
+# resolve_hanging_nodes at bp5/fe_evaluation_gl.h:150-151,167-168 -- the bit layout of deal.II's own header is not in the
+# reference, this is the library's documented one).  A fine cell whose face normal to direction d lies on a coarser neighbour:
+#   FACE_d   the face normal to d is constrained;  SIDE_d  it is the face at xi_d = 1 (else xi_d = 0);
+#   HALF_t   for the two directions t tangential to that face: the fine face covers the upper half [1/2,1] of the coarse one.
+# local_to_global of the entries ON that face names the COARSE face's DoFs (same orientation); read_dof_values interpolates
+# them to the fine face nodes, distribute_local_to_global applies the transpose.
+HANG_FACE = (1, 2, 4)
+HANG_SIDE = (8, 16, 32)
+HANG_HALF = (64, 128, 256)
+
+
+def hanging_interpolation(p):
+    """I[h][a][b] = phi_b(xi_a / 2 + h / 2): values at the fine face's nodes of the coarse 1-D basis, h = lower / upper half."""
+    nodes, _ = gll_01(p + 1)
+    out = []
+    for h in (0, 1):
+        N, _ = lagrange_tables(nodes, 0.5 * nodes + 0.5 * h)
+        out.append(N)
+    return np.stack(out)
+
+
+def resolve_hanging(mesh, u, c0=0, c1=None, transpose=False):
+    """In place on u[c0:c1] viewed as [cell][k][j][i][...]: coarse-face values -> fine-face nodal values on every constrained
+    face (transpose: the adjoint, used before the scatter).  Cells without mask bits are untouched."""
+    mask = getattr(mesh, "constraint_mask", None)
+    if mask is None:
+        return u
+    c1 = mesh.n_cells if c1 is None else c1
+    m = np.asarray(mask[c0:c1])
+    if not m.any():
+        return u
+    I = hanging_interpolation(mesh.p)
+    last = mesh.n - 1
+    for d in range(3):                                 # direction normal to the constrained face: 0 = x (index i), 1 = y, 2 = z
+        sel_d = (m & HANG_FACE[d]) != 0
+        if not sel_d.any():
+            continue
+        assert not ((m[sel_d] & (7 ^ HANG_FACE[d])) != 0).any(), "one constrained face per cell"
+        t1, t2 = [e for e in range(3) if e != d]
+        for side in (0, 1):
+            for h1 in (0, 1):
+                for h2 in (0, 1):
+                    sel = sel_d & (((m & HANG_SIDE[d]) != 0) == bool(side)) & (((m & HANG_HALF[t1]) != 0) == bool(h1)) \
+                        & (((m & HANG_HALF[t2]) != 0) == bool(h2))
+                    if not sel.any():
+                        continue
+                    ids = np.nonzero(sel)[0]
+                    # array axes of [cell][k][j][i]: direction e lives on axis 3 - e
+                    face = np.take(u[ids], side * last, axis=3 - d + 0)          # [cells][ax_hi][ax_lo][...]
+                    hi, lo = max(t1, t2), min(t1, t2)                            # remaining axes in order (higher direction first)
+                    A_hi = I[h2 if hi == t2 else h1]
+                    A_lo = I[h1 if lo == t1 else h2]
+                    if transpose:
+                        face = np.einsum("ab,ce,nac...->nbe...", A_hi, A_lo, face)
+                    else:
+                        face = np.einsum("ab,ce,nbe...->nac...", A_hi, A_lo, face)
+                    idx = [ids, slice(None), slice(None), slice(None)]
+                    idx[1 + (2 - d)] = side * last
+                    u[tuple(idx)] = face
+    return u
+
+
+class HangingBrickMesh:
+    """Two refinement levels with one planar 2:1 interface: ncx x ny x nz coarse cubes of side H on x in [0, ncx H], then
+    nfx x 2ny x 2nz cubes of side H/2 up to x = ncx H + nfx H/2.  FE_Q(p); the interface plane carries the COARSE face DoFs only;
+    the fine cells next to it are flagged (FACE_X, xi = 0 side, HALF_Y / HALF_Z) and their i = 0 entries name the coarse face's
+    DoFs.  Zero Dirichlet on the whole boundary.  Cells: coarse first, then fine, x fastest."""
+
+    def __init__(self, p, ncx, ny, nz, nfx, H=1.0, deform_amp=0.0):
+        self.p, self.n = p, p + 1
+        n = self.n
+        nodes, _ = gll_01(n)
+        NXc, NYc, NZc = p * ncx + 1, p * ny + 1, p * nz + 1
+        NXf, NYf, NZf = p * nfx, 2 * p * ny + 1, 2 * p * nz + 1       # fine lattice WITHOUT the interface plane
+        n_coarse = NXc * NYc * NZc
+        self.n_dofs = n_coarse + NXf * NYf * NZf
+        self.L = (ncx * H + nfx * H / 2, ny * H, nz * H)
+
+        def line(ncell, h):
+            N1 = p * ncell + 1
+            g = (np.arange(N1) // p + nodes[np.arange(N1) % p]) * h
+            g[-1] = ncell * h
+            return g
+        gxc, gyc, gzc = line(ncx, H), line(ny, H), line(nz, H)
+        gxf, gyf, gzf = ncx * H + line(nfx, H / 2)[1:], line(2 * ny, H / 2), line(2 * nz, H / 2)
+        Zc, Yc, Xc = np.meshgrid(gzc, gyc, gxc, indexing="ij")
+        Zf, Yf, Xf = np.meshgrid(gzf, gyf, gxf, indexing="ij")
+        coords = np.concatenate([np.stack([Xc.ravel(), Yc.ravel(), Zc.ravel()], -1), np.stack([Xf.ravel(), Yf.ravel(), Zf.ravel()], -1)])
+        i = np.arange(n)
+        cells, masks = [], []
+        for cz in range(nz):
+            for cy in range(ny):
+                for cx in range(ncx):
+                    Ig = p * cx + i[None, None, :]
+                    Jg = p * cy + i[None, :, None]
+                    Kg = p * cz + i[:, None, None]
+                    cells.append((Ig + NXc * (Jg + NYc * Kg)).ravel())
+                    masks.append(0)
+        for cz in range(2 * nz):
+            for cy in range(2 * ny):
+                for cx in range(nfx):
+                    Ig = p * cx + i[None, None, :] - 1                 # fine lattice index (-1: the interface plane)
+                    Jg = p * cy + i[None, :, None]
+                    Kg = p * cz + i[:, None, None]
+                    gid = n_coarse + Ig + NXf * (Jg + NYf * Kg) + 0 * (Jg + Kg)
+                    msk = 0
+                    if cx == 0:                                        # i = 0 entries: DoFs of the coarse face, coarse (j, k) order
+                        Jc = p * (cy // 2) + i[None, :, None]
+                        Kc = p * (cz // 2) + i[:, None, None]
+                        face = (NXc - 1) + NXc * (Jc + NYc * Kc) + 0 * i[None, None, :]
+                        gid = np.where(i[None, None, :] == 0, face, gid)
+                        msk = HANG_FACE[0] | (HANG_HALF[1] if cy % 2 else 0) | (HANG_HALF[2] if cz % 2 else 0)
+                    cells.append(gid.ravel())
+                    masks.append(msk)
+        self.l2g = np.asarray(cells, dtype=np.uint32)
+        self.constraint_mask = np.asarray(masks, dtype=np.uint32)
+        self.n_cells = self.l2g.shape[0]
+        self.n_coarse_cells = ncx * ny * nz
+        if deform_amp != 0.0:
+            coords = deform_sine(coords, self.L, deform_amp)
+        self.coords = coords
+        x, y, z = coords[:, 0], coords[:, 1], coords[:, 2]
+        if deform_amp == 0.0:
+            eps = 1e-12
+            bnd = (x < eps) | (x > self.L[0] - eps) | (y < eps) | (y > self.L[1] - eps) | (z < eps) | (z > self.L[2] - eps)
+        else:                                                          # the sine map keeps boundary points on the boundary
+            c0 = np.concatenate([np.stack([Xc.ravel(), Yc.ravel(), Zc.ravel()], -1), np.stack([Xf.ravel(), Yf.ravel(), Zf.ravel()], -1)])
+            eps = 1e-12
+            bnd = np.zeros(self.n_dofs, bool)
+            for e in range(3):
+                bnd |= (c0[:, e] < eps) | (c0[:, e] > self.L[e] - eps)
+        self.constrained = np.nonzero(bnd)[0].astype(np.uint32)
+
+    def cell_node_coords(self):
+        """positions of every cell's OWN nodes through the hanging-node interpolation of the coordinate field"""
+        n = self.n
+        X = self.coords[self.l2g.astype(np.int64)].reshape(self.n_cells, n, n, n, 3).copy()
+        return resolve_hanging(self, X)
+
+
 # ----------------------------------------------------------------------------- geometry (A.3)
 def _grad_ref(u, N, D):
     """u: [..., k, j, i] nodal values -> (g0,g1,g2) reference gradients at q-points [..., qk, qj, qi].
@@ -193,6 +335,8 @@ def jacobians(mesh, N, D, w):
     """K = J^{-1} (K[d][e] = d xi_d / d x_e, bp5/fe_evaluation_gl.h:334-343), JxW, q-point coords."""
     n = mesh.n
     Xc = mesh.coords[mesh.l2g.astype(np.int64)].reshape(mesh.n_cells, n, n, n, 3)
+    if getattr(mesh, "constraint_mask", None) is not None:   # the coordinate field is interpolated like any FE function
+        Xc = resolve_hanging(mesh, Xc.copy())
     J = np.empty((mesh.n_cells, n, n, n, 3, 3))
     for e in range(3):
         g = _grad_ref(Xc[..., e], N, D)
@@ -228,7 +372,7 @@ def apply_cells(mesh, coef, N, D, src, chunk=4096, cell_range=None, dst=None):
     for c0 in range(lo, hi, chunk):
         c1 = min(hi, c0 + chunk)
         idx = mesh.l2g[c0:c1].astype(np.int64)
-        u = src[idx].reshape(c1 - c0, n, n, n)
+        u = resolve_hanging(mesh, src[idx].reshape(c1 - c0, n, n, n), c0, c1)     # read_dof_values incl. hanging-node fix-up
         g0, g1, g2 = _grad_ref(u, N, D)
         S = coef[:, c0:c1].reshape(6, c1 - c0, n, n, n)
         t0 = S[0] * g0 + S[3] * g1 + S[4] * g2
@@ -237,6 +381,7 @@ def apply_cells(mesh, coef, N, D, src, chunk=4096, cell_range=None, dst=None):
         y = (np.einsum("ck,bj,ai,...cba->...kji", N, N, D, t0, optimize=True)
              + np.einsum("ck,bj,ai,...cba->...kji", N, D, N, t1, optimize=True)
              + np.einsum("ck,bj,ai,...cba->...kji", D, N, N, t2, optimize=True))
+        y = resolve_hanging(mesh, y, c0, c1, transpose=True)                      # distribute_local_to_global's counterpart
         np.add.at(dst, idx.ravel(), y.reshape(-1))
     return dst
 
@@ -336,6 +481,7 @@ def assemble_rhs(mesh, w_unused=None):
     _, JxW, _ = jacobians(mesh, N, D, w)
     n = mesh.n
     y = np.einsum("ck,bj,ai,...cba->...kji", N, N, N, JxW.reshape(mesh.n_cells, n, n, n), optimize=True)
+    y = resolve_hanging(mesh, y, transpose=True)
     b = np.zeros(mesh.n_dofs)
     np.add.at(b, mesh.l2g.astype(np.int64).ravel(), y.reshape(-1))
     b[mesh.constrained.astype(np.int64)] = 0.0
@@ -423,7 +569,7 @@ def l2_norm_solution(mesh, u):
     _, _, w, N, D = shape_tables(mesh.p, QUAD_GAUSS)
     _, JxW, _ = jacobians(mesh, N, D, w)
     n = mesh.n
-    uq = _interp(u[mesh.l2g.astype(np.int64)].reshape(mesh.n_cells, n, n, n), N).reshape(mesh.n_cells, -1)
+    uq = _interp(resolve_hanging(mesh, u[mesh.l2g.astype(np.int64)].reshape(mesh.n_cells, n, n, n)), N).reshape(mesh.n_cells, -1)
     return float(np.sqrt(np.sum(uq * uq * JxW)))
 
 

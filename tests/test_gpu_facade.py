@@ -90,3 +90,30 @@ def test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, 
         print(f"step-64 cycle 0 (p=3, 8 cells, 343 DoFs): solution norm {norm_ref:.7f} (GPU {vals['helmholtz_plain_norm']:.7f}); "
               f"remembered tutorial value {soft}; difference {norm_ref - soft:+.2e}")
         assert m.n_dofs == 343 and abs(norm_ref - soft) < 1e-7               # agrees to the six digits remembered
+
+
+@pytest.mark.parametrize("p", [2, 3])
+def test_facade_resolves_hanging_nodes(tmp_path, p):
+    """FEEvaluation::read_dof_values / distribute_local_to_global of the facade honour Data::constraint_mask
+    (resolve_hanging_nodes, bp5/fe_evaluation_gl.h:150-151,167-168): a user functor written like the reference's
+    LocalPoissonOperator, on a mesh with one 2:1 refined interface handed over as flat arrays, against the library's
+    hanging-node kernel and the oracle."""
+    m = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=0.03)
+    prefix = str(tmp_path / "hang")
+    s = O.deterministic_src(m.n_dofs, seed=81)
+    m.l2g.astype(np.uint32).tofile(prefix + "_l2g.bin")
+    m.coords.astype(np.float64).tofile(prefix + "_coords.bin")
+    m.constrained.astype(np.uint32).tofile(prefix + "_constrained.bin")
+    m.constraint_mask.astype(np.uint32).tofile(prefix + "_mask.bin")
+    s.tofile(prefix + "_src.bin")
+    r = subprocess.run([EXE, "hanging", str(p), prefix], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vals = {k: float(v) for k, v in re.findall(r"^(\w+) ([0-9.e+-]+)", r.stdout, flags=re.M)}
+    assert vals["functor_vs_library"] < 1e-13 and vals["unmerged_functor_vs_library"] < 1e-13
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    ref = O.apply_cells(m, O.merged_metric(m, N, D, w), N, D, s)
+    c = m.constrained.astype(np.int64)
+    ref[c] = s[c]
+    for tag in ("library", "functor", "functor_unmerged"):
+        got = np.fromfile(prefix + f"_out_{tag}.bin")
+        assert np.linalg.norm(got - ref) < 1e-13 * np.linalg.norm(ref), tag

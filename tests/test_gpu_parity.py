@@ -1173,6 +1173,77 @@ def test_block_kernel_behind_the_halo_exchange(variant):
     comm.close()
 
 
+# ------------------------------------------------------------------ hanging nodes
+def _hanging_namespace(m):
+    from types import SimpleNamespace
+    return SimpleNamespace(degree=m.p, n=m.n, n_cells=m.n_cells, n_interior_cells=m.n_cells, n_owned=m.n_dofs, n_ghost=0, n_local=m.n_dofs,
+                           n_global_dofs=m.n_dofs, l2g=m.l2g, coords=m.coords, constrained=m.constrained, n_neighbors=0,
+                           neighbor_rank=np.zeros(0, np.int32), send_offsets=np.zeros(1, np.uint32), send_indices=np.zeros(0, np.uint32),
+                           recv_offsets=np.zeros(1, np.uint32), cell_block_offsets=None, constraint_mask=m.constraint_mask, rank=0, n_ranks=1)
+
+
+@pytest.mark.parametrize("p,quad,amp", [(1, 0, 0.0), (2, 0, 0.0), (2, 1, 0.03), (3, 0, 0.03), (3, 1, 0.0), (4, 0, 0.02), (5, 0, 0.0)])
+def test_hanging_nodes_on_a_2_to_1_refined_mesh(p, quad, amp):
+    """constraint_mask path of read_dof_values / distribute_local_to_global (resolve_hanging_nodes,
+    bp5/fe_evaluation_gl.h:150-151,167-168): a mesh with one planar 2:1 interface (2x2x1 coarse cubes, then 3x4x2 cubes of
+    half the size).  The fine cells at the interface name the coarse face's DoFs and carry BP5_HANG_* masks; geometry,
+    operator, RHS, both CG solvers and the L2 norm against the oracle, whose hanging-node path is pinned by the known-answer
+    tests of tests/test_oracle_known_answers.py (null space, symmetry, energy of polynomials across the interface)."""
+    torch = _t()
+    m = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=amp)
+    assert (m.constraint_mask != 0).sum() == 8
+    _, _, w, N, D = O.shape_tables(p, quad)
+    coef_ref = O.merged_metric(m, N, D, w, O.kappa_step64)
+    op = pkg.PoissonOperator(_hanging_namespace(m), quad, pkg.COEF_STEP64)
+    assert op.mf_data.get_apply_variant() == 90
+    got = op.mf_data.coef_reference_layout(op.coef).cpu().numpy().reshape(6, m.n_cells, -1)
+    assert np.abs(got - coef_ref).max() < 1e-12 * np.abs(coef_ref).max()
+    c = m.constrained.astype(np.int64)
+
+    def A(s):
+        d = O.apply_cells(m, coef_ref, N, D, s)
+        d[c] = s[c]
+        return d
+
+    s = O.deterministic_src(m.n_dofs, seed=71)
+    dst = op.initialize_dof_vector()
+    dst.fill_(float("nan"))
+    op.vmult(dst, dev(s))
+    assert rel(dst.cpu().numpy(), A(s)) < TOL_OP
+    acc = torch.full_like(dst, 0.25)                      # cell_loop accumulates
+    op.mf_data.cell_loop(op.coef, dev(s), acc)
+    assert rel(acc.cpu().numpy() - 0.25, O.apply_cells(m, coef_ref, N, D, s)) < TOL_OP
+    b = op.assemble_rhs()
+    b_ref = O.assemble_rhs(m)
+    assert rel(b.cpu().numpy(), b_ref) < TOL_OP
+    its = 3 if p == 1 else 6                              # (p = 1 has only a handful of free DoFs: CG is exact after a few steps)
+    xr, _, _ = O.cg_plain(A, b_ref, its)
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(its, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == its and rel(x.cpu().numpy(), xr) < TOL_CG
+    assert abs(op.l2_norm_solution(x) - O.l2_norm_solution(m, xr)) < 1e-11 * O.l2_norm_solution(m, xr)
+    d = op.mf_data.get_data()
+    import ctypes as C
+    masks = np.zeros(m.n_cells, np.uint32)
+    pkg.lib().bp5_copy_d2h(masks.ctypes.data, C.c_void_p(d.constraint_mask), masks.nbytes)
+    assert np.array_equal(masks, m.constraint_mask)       # MatrixFree::Data::constraint_mask mirrors the input
+    with pytest.raises(pkg.BP5Error):
+        op.mf_data.set_apply_variant(3)                   # no other kernel honours the masks
+    with pytest.raises(pkg.BP5Error):
+        op.compute_diagonal()
+    # masks the library does not implement are refused at create time
+    bad = _hanging_namespace(m)
+    bad.constraint_mask = m.constraint_mask.copy()
+    bad.constraint_mask[-1] = 1 | 2                       # two constrained faces
+    with pytest.raises(pkg.BP5Error):
+        pkg.PoissonOperator(bad, quad)
+    bad.constraint_mask[-1] = 1 << 9                      # unknown bit (isolated hanging edge)
+    with pytest.raises(pkg.BP5Error):
+        pkg.PoissonOperator(bad, quad)
+
+
 # ------------------------------------------------------------------ edge cases
 def test_single_cell_and_tiny_meshes():
     """one cell (every DoF on the Dirichlet boundary except the interior ones), p = 1 and p = 8"""

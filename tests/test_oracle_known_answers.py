@@ -246,3 +246,50 @@ def test_step64_helmholtz_solution_norms_agree_with_the_tutorial_output():
         x, k, res = O.cg_plain(A, b, m.n_dofs, tol=1e-12 * np.linalg.norm(b))
         assert res <= 1e-12 * np.linalg.norm(b) and k < m.n_dofs
         assert f"{O.l2_norm_solution(m, x):.6g}" == text
+
+
+@pytest.mark.parametrize("p,amp", [(1, 0.0), (2, 0.0), (3, 0.0), (4, 0.0), (2, 0.03), (3, 0.04)])
+def test_hanging_node_path_of_the_oracle(p, amp):
+    """Known answers for the oracle's hanging-node treatment (resolve_hanging, HangingBrickMesh; the reference's call sites are
+    bp5/fe_evaluation_gl.h:150-151,167-168, the arithmetic lives in deal.II).  One planar 2:1 interface.
+    * interpolation: the coordinate field, gathered through local_to_global and fixed up, gives every cell its OWN GLL nodes
+      (undeformed mesh: compared with the analytic node positions);
+    * the quadrature weights sum to the volume; constants are in the null space; the operator is symmetric (the scatter is the
+      adjoint of the gather);
+    * energy identity across the interface: for u = a.x (any mesh) and u = x^2 + y z (p >= 2, undeformed: it lies in the
+      conforming space on both sides of the interface) u^T A u equals the exact integral of |grad u|^2;
+    * sum of the right-hand side = volume."""
+    m = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=amp)
+    n = m.n
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    vol_exact = m.L[0] * m.L[1] * m.L[2]
+    if amp == 0.0:
+        X = m.cell_node_coords()
+        nodes, _ = O.gll_01(n)
+        for c in range(m.n_coarse_cells, m.n_cells):          # fine cells: axis-aligned cubes of side H/2 on GLL nodes
+            lo, hi = X[c].reshape(-1, 3).min(0), X[c].reshape(-1, 3).max(0)
+            assert np.allclose(hi - lo, 0.25, atol=1e-14)
+            for e, ax in ((0, 2), (1, 1), (2, 0)):
+                line = np.moveaxis(X[c][..., e], ax, 0).reshape(n, -1)
+                assert np.abs(line - (lo[e] + 0.25 * nodes)[:, None]).max() < 1e-14
+    _, JxW, _ = O.jacobians(m, N, D, w)
+    vol = JxW.sum()
+    if amp == 0.0:
+        assert abs(vol - vol_exact) < 1e-13
+    coef = O.merged_metric(m, N, D, w)
+    assert np.abs(O.apply_cells(m, coef, N, D, np.ones(m.n_dofs))).max() < 1e-12
+    rng = np.random.default_rng(4)
+    u, v = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    assert abs(v @ O.apply_cells(m, coef, N, D, u) - u @ O.apply_cells(m, coef, N, D, v)) < 1e-11 * abs(v @ O.apply_cells(m, coef, N, D, u))
+    a = np.array([0.3, -1.1, 0.7])
+    ul = m.coords @ a
+    assert abs(ul @ O.apply_cells(m, coef, N, D, ul) - (a @ a) * vol) < 1e-12 * (a @ a) * vol
+    if p >= 2 and amp == 0.0:
+        x, y, z = m.coords.T
+        uq = x * x + y * z
+        Lx, Ly, Lz = m.L
+        exact = 4 * Lx ** 3 / 3 * Ly * Lz + Lx * Ly * Lz ** 3 / 3 + Lx * Ly ** 3 / 3 * Lz
+        assert abs(uq @ O.apply_cells(m, coef, N, D, uq) - exact) < 1e-12 * exact
+    m2 = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=amp)
+    m2.constrained = np.zeros(0, np.uint32)                     # unconstrained RHS: sum_i int phi_i = volume
+    assert abs(O.assemble_rhs(m2).sum() - vol) < 1e-12 * vol
