@@ -901,12 +901,15 @@ static int halo_streams(bp5_mf *mf)
   for (hipEvent_t &e : mf->ev_halo) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return BP5_OK;
 }
-extern "C" int bp5_mf_set_overlap(bp5_mf *mf, int on)
+extern "C" int bp5_mf_set_overlap(bp5_mf *mf, int mode)
 {
-  if (!mf) return fail(BP5_ERR_INVALID, "null handle");
-  mf->overlap = on != 0;
+  if (!mf || mode < 0 || mode > 2) return fail(BP5_ERR_INVALID, "bad argument");
+  mf->overlap = mode;
   return BP5_OK;
 }
+// auto: the split into interior / boundary / interior launches and its four cross-stream dependencies cost 50-80 us per
+// application on one GPU (profiles/r2 p_*), the exchange it hides is one DoF plane each way: worth it on large slabs only
+static bool overlap_wanted(const bp5_mf *mf) { return mf->overlap == 1 || (mf->overlap == 2 && mf->n_interior >= 1000000u); }
 // ghost gather: owners send their interface values (packed through send_indices), ghosts are
 // received straight into the vector's ghost range (contiguous per neighbour)
 extern "C" int bp5_halo_gather_start(bp5_mf *mf, double *v)
@@ -921,8 +924,9 @@ extern "C" int bp5_halo_gather_start(bp5_mf *mf, double *v)
     hipLaunchKernelGGL(pack_kernel, dim3((ns + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx, ns, v, mf->d_sendbuf);
     KERNEL_CHECK();
   }
-  hipStream_t cs = mf->overlap ? mf->comm_stream : mf->stream;
-  if (mf->overlap) { // the exchange starts once the values are packed (and everything before them on the compute stream is done)
+  mf->overlap_now = overlap_wanted(mf);
+  hipStream_t cs = mf->overlap_now ? mf->comm_stream : mf->stream;
+  if (mf->overlap_now) { // the exchange starts once the values are packed (and everything before them on the compute stream is done)
     HIP_TRY(hipEventRecord(mf->ev_halo[0], mf->stream));
     HIP_TRY(hipStreamWaitEvent(cs, mf->ev_halo[0], 0));
   }
@@ -933,7 +937,7 @@ extern "C" int bp5_halo_gather_start(bp5_mf *mf, double *v)
     if (rc) NCCL_TRY(ncclRecv(v + mf->n_owned + mf->recv_off[k], rc, ncclDouble, mf->neighbors[k], mf->comm->comm, cs));
   }
   NCCL_TRY(ncclGroupEnd());
-  if (mf->overlap) HIP_TRY(hipEventRecord(mf->ev_halo[1], cs));
+  if (mf->overlap_now) HIP_TRY(hipEventRecord(mf->ev_halo[1], cs));
   return BP5_OK;
 }
 extern "C" int bp5_halo_gather_finish(bp5_mf *mf, double *v)
@@ -941,7 +945,7 @@ extern "C" int bp5_halo_gather_finish(bp5_mf *mf, double *v)
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
   if (mf->neighbors.empty()) return BP5_OK;
   if (!mf->comm || !mf->comm_stream) return fail(BP5_ERR_INVALID, "bp5_halo_gather_finish without bp5_halo_gather_start");
-  if (mf->overlap) HIP_TRY(hipStreamWaitEvent(mf->stream, mf->ev_halo[1], 0)); // later compute work sees the ghosts
+  if (mf->overlap_now) HIP_TRY(hipStreamWaitEvent(mf->stream, mf->ev_halo[1], 0)); // later compute work sees the ghosts
   return BP5_OK;
 }
 extern "C" int bp5_halo_gather(bp5_mf *mf, double *v)
@@ -957,8 +961,9 @@ extern "C" int bp5_halo_scatter_add_start(bp5_mf *mf, double *v)
   if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
   HIP_TRY(hipSetDevice(mf->device));
   BP5_TRY(halo_streams(mf));
-  hipStream_t cs = mf->overlap ? mf->comm_stream : mf->stream;
-  if (mf->overlap) { // the ghost entries are complete at this point of the compute stream
+  mf->overlap_now = overlap_wanted(mf);
+  hipStream_t cs = mf->overlap_now ? mf->comm_stream : mf->stream;
+  if (mf->overlap_now) { // the ghost entries are complete at this point of the compute stream
     HIP_TRY(hipEventRecord(mf->ev_halo[2], mf->stream));
     HIP_TRY(hipStreamWaitEvent(cs, mf->ev_halo[2], 0));
   }
@@ -969,7 +974,7 @@ extern "C" int bp5_halo_scatter_add_start(bp5_mf *mf, double *v)
     if (sc) NCCL_TRY(ncclRecv(mf->d_recvbuf + mf->send_off[k], sc, ncclDouble, mf->neighbors[k], mf->comm->comm, cs));
   }
   NCCL_TRY(ncclGroupEnd());
-  if (mf->overlap) HIP_TRY(hipEventRecord(mf->ev_halo[3], cs));
+  if (mf->overlap_now) HIP_TRY(hipEventRecord(mf->ev_halo[3], cs));
   return BP5_OK;
 }
 extern "C" int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v)
@@ -977,7 +982,7 @@ extern "C" int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v)
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
   if (mf->neighbors.empty()) return BP5_OK;
   if (!mf->comm || !mf->comm_stream) return fail(BP5_ERR_INVALID, "bp5_halo_scatter_add_finish without bp5_halo_scatter_add_start");
-  if (mf->overlap) HIP_TRY(hipStreamWaitEvent(mf->stream, mf->ev_halo[3], 0));
+  if (mf->overlap_now) HIP_TRY(hipStreamWaitEvent(mf->stream, mf->ev_halo[3], 0));
   for (size_t k = 0; k < mf->neighbors.size(); ++k) { // per neighbour: indices distinct -> race-free, fixed order
     const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k];
     if (!sc) continue;
@@ -1056,7 +1061,7 @@ static int apply_overlapped(bp5_mf *mf, const double *coef, double *src, double 
   ApplyPhases ph;
   BP5_TRY(bp5_halo_gather_start(mf, src));
   int st = phases_begin(mf, dst, overwrite, ph);
-  if (st == BP5_OK && (!aligned || !mf->overlap)) {
+  if (st == BP5_OK && (!aligned || !overlap_wanted(mf))) {
     st = bp5_halo_gather_finish(mf, src);
     if (st == BP5_OK) st = phases_range(mf, coef, src, dst, 0, mf->n_cells, ph);
     BP5_TRY(phases_end(mf, dst, ph, st));

@@ -79,7 +79,8 @@ struct bp5_mf {
   // halo exchange on its own stream (overlap with interior cells): created on first use
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_halo[4] = {nullptr, nullptr, nullptr, nullptr}; // packed / gathered / ghosts ready / received
-  bool overlap = true;        // MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241)
+  int overlap = 2;            // MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241): 0 off, 1 on, 2 auto
+  bool overlap_now = false;   // the decision for the exchange in flight (set by *_start)
   bool cg_fusion = true;      // SolverCGFullMerge: dot products inside the block kernel's write-out when the plan allows
   bool defer_combine = false; // block kernel on cell ranges: partial slab now, ONE combine pass after the last range
   // solver workspace

@@ -136,9 +136,10 @@ class MatrixFree:
         """BP5_GEOM_MERGED6 (reference representation, default) or BP5_GEOM_AFFINE (affine meshes)."""
         _lib.check(_lib.lib().bp5_mf_set_geometry_mode(self.handle, int(mode)))
 
-    def set_overlap(self, on=True):
-        """== AdditionalData::overlap_communication_computation (bp5/step-64.cu:241), default on."""
-        _lib.check(_lib.lib().bp5_mf_set_overlap(self.handle, 1 if on else 0))
+    def set_overlap(self, mode=True):
+        """== AdditionalData::overlap_communication_computation (bp5/step-64.cu:241): True / 1 on, False / 0 off, 2 = the
+        library decides by the slab's size (default)."""
+        _lib.check(_lib.lib().bp5_mf_set_overlap(self.handle, int(mode)))
 
     def set_cg_fusion(self, on=True):
         """SolverCGFullMerge: dot products inside the block kernel's write-out (default) or as a separate kernel."""

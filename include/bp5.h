@@ -290,9 +290,11 @@ int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v);
 int bp5_halo_gather(bp5_mf *mf, double *v);
 int bp5_halo_scatter_add(bp5_mf *mf, double *v);
 int bp5_halo_zero_ghosts(bp5_mf *mf, double *v);
-/* == MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241; default on, as in the reference):
- *    off = the exchange stays on the handle's stream and the cell loop runs unsplit */
-int bp5_mf_set_overlap(bp5_mf *mf, int on);
+/* == MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241).  mode 1: on (the reference's setting);
+ *    0: off -- the exchange stays on the handle's stream and the cell loop runs unsplit; 2 (default): the library decides -- on for
+ *    slabs of >= 1e6 interior cells, off below: the split costs 50-80 us per application (three launches, four cross-stream
+ *    dependencies) and hides one DoF plane each way (profiles/r2 README, p_*) */
+int bp5_mf_set_overlap(bp5_mf *mf, int mode);
 /* distributed vmult == PoissonOperator::vmult on more than one rank (bp5/step-64.cu:263-276 with the cell_loop of :274):
  *    ghost gather started; first part of the interior cells [0, n_interior_cells) underneath it; gather finished; the cells
  *    that touch ghosts; ghost contributions sent to their owners (atomic kernels: under the rest of the interior cells; the

@@ -862,7 +862,14 @@ def test_medium_size_against_c_oracle():
     (2, (81, 80, 79), 0, 0.03, 0, {}, 0), (5, (33, 32, 31), 1, 0.03, 1, {}, 0), (7, (23, 22, 21), 0, 0.03, 1, {}, 0),
     (8, (20, 19, 18), 1, 0.03, 1, {}, 0),
     (4, (60, 59, 58), 0, 0.0, 1, dict(geometry="affine"), 10), (6, (30, 29, 28), 0, 0.0, 1, dict(geometry="affine"), 0),
-    (4, (86, 84, 82), 1, 0.0, 1, dict(geometry="affine", cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56)])
+    (4, (86, 84, 82), 1, 0.0, 1, dict(geometry="affine", cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),
+    # the deterministic block kernel on the other degrees at the BASELINE sizes: config 5 (p = 6, 61^3, deformed, 49 430 863 DoFs) and
+    # config 4 (~5e7 DoFs) for p = 2, 3, 5, 7 -- bricks sized for the LDS accumulator, partial bricks at the mesh edges
+    (6, (61, 61, 61), 0, 0.05, 1, dict(cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1), 56),
+    (5, (73, 73, 73), 0, 0.03, 1, dict(cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1), 56),
+    (7, (52, 52, 52), 1, 0.03, 1, dict(cell_block=(4, 2, 2), dof_numbering=1, cell_block_order=1), 56),
+    (3, (122, 122, 122), 0, 0.03, 1, dict(cell_block=(8, 4, 4), dof_numbering=1, cell_block_order=1), 56),
+    (2, (184, 184, 184), 0, 0.0, 1, dict(cell_block=(8, 8, 4), dof_numbering=1, cell_block_order=1), 56)])
 def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     """Size-independent properties at BASELINE scale: constants in the null space of the cell
     loop, symmetry, linearity; CG residual consistency.  The third case is the bench's mesh ordering
@@ -906,7 +913,7 @@ def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
         # atomic pencil kernel over repeated launches, bitwise reproducible
         # (regressions: accumulator cleared only up to the first block's length; LDS write in flight at a
         # loop-header barrier, tests/test_isa_checks.py)
-        mf.set_apply_variant(3 if p == 4 else 1)
+        mf.set_apply_variant(3 if p == 4 else 110 if p == 2 else 1)   # an atomic kernel as reference
         ref = mf.initialize_dof_vector()
         op.vmult(ref, u)
         mf.set_apply_variant(0)
@@ -1046,6 +1053,7 @@ def test_halo_exchange_through_rccl_with_a_self_neighbour():
     refw2[torch.from_numpy(send_idx.astype(np.int64)).cuda()] += refw2[no:]
     refw2[no:] = 0.0
     busy = torch.zeros(1 << 22, dtype=torch.float64, device="cuda:0")
+    assert L.bp5_mf_set_overlap(h, 1) == 0                    # (the default, 2, overlaps on large slabs only)
     assert L.bp5_halo_gather_start(h, ptr(v2)) == 0
     for _ in range(4):
         assert L.bp5_vec_fill(h, ptr(busy), 1.0, busy.numel()) == 0
@@ -1121,6 +1129,7 @@ def test_block_kernel_behind_the_halo_exchange(variant):
     src = torch.rand(no + ng, dtype=torch.float64, device="cuda:0", generator=g)
     src[no:] = 0.0
     outs = []
+    assert L.bp5_mf_set_overlap(h, 1) == 0                # force the overlapped schedule (the default decides by slab size)
     for v in (3, variant):
         op.mf_data.set_apply_variant(v)
         op.mf_data.set_block_workgroups(8)

@@ -48,8 +48,8 @@ for name in ("slab + exchange, overlapped", "slab + exchange, sequential", "same
     else:
         comm, msh = None, pkg.BrickMesh(p, (n, n, layers), h=1.0 / n, **kw)
     op = pkg.PoissonOperator(msh, 0, pkg.COEF_STEP64, comm=comm)
-    if name.endswith("sequential"):
-        op.mf_data.set_overlap(False)
+    if name.startswith("slab"):
+        op.mf_data.set_overlap(0 if name.endswith("sequential") else 1)
     b = op.assemble_rhs()
     x = op.initialize_dof_vector()
     Solver(pkg.IterationNumberControl(5, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
