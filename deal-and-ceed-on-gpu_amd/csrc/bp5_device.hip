@@ -120,6 +120,9 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     for (uint32_t s = 0; s < ns; ++s)
       if (d->send_indices_host[s] >= d->n_owned) { return fail(BP5_ERR_INVALID, "send index out of owned range"); }
     BP5_TRY(upload(&mf->d_send_idx, d->send_indices_host, ns));
+    std::vector<uint8_t> sd(ns);
+    for (uint32_t s = 0; s < ns; ++s) sd[s] = mf->h_constrained[d->send_indices_host[s]] ? 1 : 0;
+    BP5_TRY(upload(&mf->d_send_dirichlet, sd.data(), sd.size()));
     HIP_TRY(hipMalloc((void **)&mf->d_sendbuf, std::max<size_t>(ns, 1) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&mf->d_recvbuf, std::max<size_t>(ns, 1) * sizeof(double)));
   } else if (d->n_ghost) { return fail(BP5_ERR_INVALID, "ghosts without a halo plan"); }
@@ -147,7 +150,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell, mf->d_hang_mask, mf->d_hang_I};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell, mf->d_hang_mask, mf->d_hang_I, mf->d_send_dirichlet};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
@@ -534,7 +537,7 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
     if (mf->fuse.on) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = cg.x; cr.cg_state = mf->d_st;
-      const uint32_t grid = std::min<uint32_t>(cg.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols);
+      const uint32_t grid = std::min<uint32_t>(cg.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u); // 1024 columns stay free for the exchange
       hipLaunchKernelGGL((combine_runs_kernel<false, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
       mf->fuse.n_cols += grid;
@@ -986,8 +989,15 @@ extern "C" int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v)
   for (size_t k = 0; k < mf->neighbors.size(); ++k) { // per neighbour: indices distinct -> race-free, fixed order
     const uint32_t sc = mf->send_off[k + 1] - mf->send_off[k];
     if (!sc) continue;
-    hipLaunchKernelGGL(unpack_add_kernel, dim3((sc + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx + mf->send_off[k], sc,
-                       mf->d_recvbuf + mf->send_off[k], v);
+    if (mf->fuse.on) { // fused CG dot products: correct the sums the write-out formed with the local part of these DoFs
+      const uint32_t grid = std::min<uint32_t>((sc + 255) / 256, 1024u / (uint32_t)mf->neighbors.size());
+      hipLaunchKernelGGL(unpack_add_dots_kernel, dim3(grid), dim3(256), 0, mf->stream, mf->d_send_idx + mf->send_off[k],
+                         mf->d_send_dirichlet + mf->send_off[k], sc, mf->d_recvbuf + mf->send_off[k], v, mf->fuse.r, mf->d_partials,
+                         mf->fuse.n_cols, mf->d_st);
+      mf->fuse.n_cols += grid;
+    } else
+      hipLaunchKernelGGL(unpack_add_kernel, dim3((sc + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx + mf->send_off[k], sc,
+                         mf->d_recvbuf + mf->send_off[k], v);
     KERNEL_CHECK();
   }
   return bp5_halo_zero_ghosts(mf, v);
@@ -1171,6 +1181,28 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
                         uint32_t *n_cols = nullptr)
 {
   const bool dist = mf->comm && !mf->neighbors.empty(); // halo exchange: whenever there are neighbours (tests: a self neighbour)
+  if (dist && fuse_r) {
+    // unsplit exchange + fused dot products: gather, ONE fused launch over all cells (p.v is a sum over cells, so it needs no
+    // owner bookkeeping; v.v, r.v, r.r run over owned DoFs), then the ghost contributions travel to their owners, whose
+    // unpack kernel corrects v.v and r.v for what it adds
+    BP5_TRY(bp5_halo_gather(mf, src));
+    BP5_TRY(prof.mark(0));
+    BP5_TRY(prof.mark(1));
+    if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
+    mf->fuse.on = true; mf->fuse.p = src; mf->fuse.r = fuse_r; mf->fuse.n_cols = 0;
+    int st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
+    const bool marked = prof.on && mf->prof_mark == nullptr;
+    mf->prof_mark = nullptr;
+    if (st == BP5_OK && !marked) st = prof.mark(2);
+    if (st == BP5_OK) st = prof.mark(3);
+    if (prof.on) prof.used += 4;
+    if (st == BP5_OK) st = bp5_halo_scatter_add(mf, dst); // (fuse.on: dot-product corrections inside)
+    *n_cols = mf->fuse.n_cols;
+    mf->fuse = bp5_mf::Fuse{};
+    BP5_TRY(st);
+    BP5_TRY(bp5_halo_zero_ghosts(mf, src));
+    return bp5_copy_constrained(mf, src, dst); // the owner of a Dirichlet interface DoF has just been handed a contribution
+  }
   if (dist) { // phased application: the exchange overlaps the interior cells (apply_overlapped)
     BP5_TRY(prof.mark(0));
     BP5_TRY(prof.mark(1));
@@ -1296,7 +1328,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     KERNEL_CHECK();
     // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
     bool &fused = fused_dots;
-    if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty()) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
+    if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty() && overlap_wanted(mf)) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
         effective_variant(mf, 0, mf->n_cells) == 56) {
       bp5_mf::DevPlan *dp = nullptr;
       BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));

@@ -75,6 +75,7 @@ struct bp5_mf {
   std::vector<int> neighbors;
   std::vector<uint32_t> send_off, recv_off;
   double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+  uint8_t *d_send_dirichlet = nullptr; // per send index: the owner DoF is a Dirichlet DoF
   bp5_comm *comm = nullptr;
   // halo exchange on its own stream (overlap with interior cells): created on first use
   hipStream_t comm_stream = nullptr;

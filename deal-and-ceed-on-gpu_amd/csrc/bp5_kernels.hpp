@@ -2360,6 +2360,37 @@ static __global__ void unpack_add_kernel(const uint32_t *idx, uint32_t n, const 
   if (i < n) v[idx[i]] += buf[i]; // indices of one neighbour are distinct
 }
 
+// the same for a solve with fused dot products (SolverCGFullMerge on the block kernel): the operator's write-out has already
+// counted the LOCAL sums of these owner DoFs in v.v and r.v; adding the neighbour's contribution c changes them by
+// (v + c)^2 - v^2 and r c -- accumulated here into columns [col0, col0 + gridDim.x) of the partial-sum rows (rows 0 and 3,
+// p.v and r.r, do not change: p.v is a sum over cells, r.r does not involve v)
+// A Dirichlet DoF among them keeps the value the write-out gave it (v = p): whatever the neighbour's cells contributed to that
+// row is discarded, as copy_constrained_values would do afterwards (bp5/step-64.cu:275).
+static __global__ void __launch_bounds__(256) unpack_add_dots_kernel(const uint32_t *idx, const uint8_t *dirichlet, uint32_t n, const double *buf, double *v,
+                                                                     const double *r, double *partials, uint32_t col0, const int *state)
+{
+  if (state[0]) return;
+  __shared__ double red[2][4];
+  double dvv = 0.0, drv = 0.0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    if (dirichlet[i]) continue;
+    const uint32_t g = idx[i];
+    const double c = buf[i], vo = v[g], vn = vo + c;
+    v[g] = vn;
+    dvv += vn * vn - vo * vo;
+    drv += r[g] * c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { dvv += __shfl_down(dvv, off, 64); drv += __shfl_down(drv, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dvv; red[1][threadIdx.x >> 6] = drv; }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int t = threadIdx.x;
+    const double svv = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), srv = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    partials[t * PARTIAL_STRIDE + col0 + blockIdx.x] = (t == 1 || t == 5) ? svv : (t == 2 || t == 4) ? srv : 0.0; // D == 1: rows 5, 4 mirror 1, 2
+  }
+}
+
 constexpr int VB = 256;      // threads per block of streaming kernels
 constexpr int MAXBLK = 2048; // grid cap of the streaming kernels (<= PARTIAL_STRIDE)
 

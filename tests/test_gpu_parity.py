@@ -1104,6 +1104,23 @@ def test_halo_exchange_through_rccl_with_a_self_neighbour():
     comm.close()
 
 
+def _consistent_self_glue(m1):
+    """send indices for a self-neighbour exchange: ghost DoF j is glued to an owned DoF with the SAME Dirichlet status (as on a real
+    partitioned mesh, where a ghost is a copy of its owner): free ghosts to the last free owned DoFs, Dirichlet ghosts to Dirichlet ones"""
+    no, ng = m1.n_owned, m1.n_ghost
+    con = np.zeros(no + ng, bool)
+    con[m1.constrained.astype(np.int64)] = True
+    free_owned = np.nonzero(~con[:no])[0][::-1]
+    dir_owned = np.nonzero(con[:no])[0][::-1]
+    send, kf, kd = np.zeros(ng, np.uint32), 0, 0
+    for j in range(ng):
+        if con[no + j]:
+            send[j] = dir_owned[kd]; kd += 1
+        else:
+            send[j] = free_owned[kf]; kf += 1
+    return send
+
+
 @pytest.mark.parametrize("variant", [56, 3])
 def test_block_kernel_behind_the_halo_exchange(variant):
     """The bench's rank-local configuration for ranks > 0 (brick-ordered slab mesh with a ghost plane, block kernel with
@@ -1115,7 +1132,7 @@ def test_block_kernel_behind_the_halo_exchange(variant):
     p, cells = 4, (9, 8, 10)
     m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=2, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
     ng, no = m1.n_ghost, m1.n_owned
-    send_idx = np.arange(no - ng, no, dtype=np.uint32)
+    send_idx = _consistent_self_glue(m1)
     mesh = SimpleNamespace(degree=p, n=p + 1, cells=cells, n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
                            n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
                            n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32), send_indices=send_idx,
@@ -1174,7 +1191,22 @@ def test_block_kernel_behind_the_halo_exchange(variant):
         assert abs(float(torch.linalg.norm((Ax - b)[:no])) - ctl.last_value()) < 1e-9 * ctl.initial_value()
         xs.append(x)
     if variant == 56:
-        assert torch.equal(xs[0], xs[1])                  # the whole solve is bitwise independent of the schedule
+        # overlap on: separate dot-product kernel; overlap off (unsplit exchange): the dot products are formed inside the block
+        # kernel on every rank's cells and the owners' unpack kernel corrects v.v and r.v for the contributions it adds
+        assert float((xs[0] - xs[1]).abs().max()) < 1e-11 * float(xs[1].abs().max())
+        assert L.bp5_mf_set_overlap(h, 0) == 0
+        sols = []
+        for fused in (True, False, True):
+            op.mf_data.set_cg_fusion(fused)
+            x = op.initialize_dof_vector()
+            ctl = pkg.IterationNumberControl(10, 0.0)
+            pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+            assert ctl.dot_products_fused == fused
+            sols.append(x)
+        assert torch.equal(sols[0], sols[2])              # fixed summation order: bitwise reproducible
+        assert torch.equal(sols[0], xs[1])                # (the unsplit solve above took the fused path too)
+        assert torch.equal(sols[1], xs[0])                # separate dot products: bitwise independent of the exchange schedule
+        assert float((sols[0] - sols[1]).abs().max()) < 1e-11 * float(sols[1].abs().max())
     else:
         assert float((xs[0] - xs[1]).abs().max()) < 1e-11 * float(xs[1].abs().max())
     op.mf_data.synchronize()

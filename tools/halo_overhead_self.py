@@ -22,6 +22,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bp5_pkg
 
 pkg = bp5_pkg.load()
+
+def consistent_self_glue(m1):
+    """send indices for a self-neighbour exchange: ghost DoF j is glued to an owned DoF with the SAME Dirichlet status (as on a real
+    partitioned mesh, where a ghost is a copy of its owner): free ghosts to the last free owned DoFs, Dirichlet ghosts to Dirichlet ones"""
+    no, ng = m1.n_owned, m1.n_ghost
+    con = np.zeros(no + ng, bool)
+    con[m1.constrained.astype(np.int64)] = True
+    free_owned = np.nonzero(~con[:no])[0][::-1]
+    dir_owned = np.nonzero(con[:no])[0][::-1]
+    send, kf, kd = np.zeros(ng, np.uint32), 0, 0
+    for j in range(ng):
+        if con[no + j]:
+            send[j] = dir_owned[kd]; kd += 1
+        else:
+            send[j] = free_owned[kf]; kf += 1
+    return send
 ap = argparse.ArgumentParser()
 ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--rank", type=int, default=3)
@@ -38,7 +54,7 @@ layers = m1.n_cells // (n * n)
 mesh = SimpleNamespace(degree=p, n=p + 1, cells=(n, n, nz), n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
                        n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
                        n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32),
-                       send_indices=np.arange(no - ng, no, dtype=np.uint32), recv_offsets=np.asarray([0, ng], np.uint32),
+                       send_indices=consistent_self_glue(m1), recv_offsets=np.asarray([0, ng], np.uint32),
                        cell_block_offsets=m1.cell_block_offsets, rank=0, n_ranks=1, h=1.0 / n, deform_amp=0.0)
 Solver = pkg.SolverCGFullMerge if args.solver == "merged" else pkg.SolverCG
 res = {}
