@@ -991,15 +991,18 @@ extern "C" int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v)
     if (!sc) continue;
     if (mf->fuse.on) { // fused CG dot products: correct the sums the write-out formed with the local part of these DoFs
       const uint32_t grid = std::min<uint32_t>((sc + 255) / 256, 1024u / (uint32_t)mf->neighbors.size());
+      const uint32_t ng = mf->fuse.ghosts_zeroed ? 0u : mf->n_ghost; // the first of these launches also zeroes both ghost ranges
       hipLaunchKernelGGL(unpack_add_dots_kernel, dim3(grid), dim3(256), 0, mf->stream, mf->d_send_idx + mf->send_off[k],
                          mf->d_send_dirichlet + mf->send_off[k], sc, mf->d_recvbuf + mf->send_off[k], v, mf->fuse.r, mf->d_partials,
-                         mf->fuse.n_cols, mf->d_st);
+                         mf->fuse.n_cols, mf->d_st, v + mf->n_owned, const_cast<double *>(mf->fuse.p) + mf->n_owned, ng);
       mf->fuse.n_cols += grid;
+      mf->fuse.ghosts_zeroed = true;
     } else
       hipLaunchKernelGGL(unpack_add_kernel, dim3((sc + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx + mf->send_off[k], sc,
                          mf->d_recvbuf + mf->send_off[k], v);
     KERNEL_CHECK();
   }
+  if (mf->fuse.on && mf->fuse.ghosts_zeroed) return BP5_OK;
   return bp5_halo_zero_ghosts(mf, v);
 }
 extern "C" int bp5_halo_scatter_add(bp5_mf *mf, double *v)
@@ -1196,12 +1199,14 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
     if (st == BP5_OK && !marked) st = prof.mark(2);
     if (st == BP5_OK) st = prof.mark(3);
     if (prof.on) prof.used += 4;
-    if (st == BP5_OK) st = bp5_halo_scatter_add(mf, dst); // (fuse.on: dot-product corrections inside)
+    if (st == BP5_OK) st = bp5_halo_scatter_add(mf, dst); // (fuse.on: dot-product corrections + ghost zeroing inside)
     *n_cols = mf->fuse.n_cols;
+    const bool ghosts_zeroed = mf->fuse.ghosts_zeroed;
     mf->fuse = bp5_mf::Fuse{};
     BP5_TRY(st);
-    BP5_TRY(bp5_halo_zero_ghosts(mf, src));
-    return bp5_copy_constrained(mf, src, dst); // the owner of a Dirichlet interface DoF has just been handed a contribution
+    if (!ghosts_zeroed) BP5_TRY(bp5_halo_zero_ghosts(mf, src)); // (a rank that owns no interface DoFs launched no unpack kernel)
+    // no Dirichlet copy: the write-out stored v = p on this rank's Dirichlet rows and the unpack kernel leaves them alone
+    return BP5_OK;
   }
   if (dist) { // phased application: the exchange overlaps the interior cells (apply_overlapped)
     BP5_TRY(prof.mark(0));

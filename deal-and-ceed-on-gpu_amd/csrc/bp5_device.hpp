@@ -118,6 +118,7 @@ struct bp5_mf {
     bool on = false;
     const double *p = nullptr, *r = nullptr;
     uint32_t n_cols = 0; // columns of d_partials written so far (block kernel workgroups, then the combine pass)
+    bool ghosts_zeroed = false; // the exchange's unpack kernel has zeroed the ghost ranges of v and p
   } fuse;
   std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
   struct DevMarch { uint32_t *team_off = nullptr, *entries = nullptr; uint32_t n_teams = 0; };

@@ -2367,9 +2367,13 @@ static __global__ void unpack_add_kernel(const uint32_t *idx, uint32_t n, const 
 // A Dirichlet DoF among them keeps the value the write-out gave it (v = p): whatever the neighbour's cells contributed to that
 // row is discarded, as copy_constrained_values would do afterwards (bp5/step-64.cu:275).
 static __global__ void __launch_bounds__(256) unpack_add_dots_kernel(const uint32_t *idx, const uint8_t *dirichlet, uint32_t n, const double *buf, double *v,
-                                                                     const double *r, double *partials, uint32_t col0, const int *state)
+                                                                     const double *r, double *partials, uint32_t col0, const int *state,
+                                                                     double *ghosts_a, double *ghosts_b, uint32_t n_ghost)
 {
   if (state[0]) return;
+  // the ghost ranges of v (just sent to the owners) and of src (read by this application's cells) are zeroed here instead of by
+  // two more launches
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_ghost; i += gridDim.x * 256u) { ghosts_a[i] = 0.0; ghosts_b[i] = 0.0; }
   __shared__ double red[2][4];
   double dvv = 0.0, drv = 0.0;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
