@@ -1331,6 +1331,17 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
     hipLaunchKernelGGL(cgm_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
+    // update kernels: U chunks of 256 pairs per loop trip, all loads of a trip ahead of its stores (A/B knob for tools:
+    // BP5_UPDATE_UNROLL = 1 | 2 | 4; profiles/r2: 1.03 / 1.00 / 0.99 ms per iteration at 1e8 DoFs; default 4)
+    static const int unroll = [] { const char *e = getenv("BP5_UPDATE_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 1 || u == 2) ? u : 4; }();
+    const int gridu = stream_grid(n, 2 * unroll);
+    auto launch_update = [&](int mode) {
+#define BP5_UPD(M, U) hipLaunchKernelGGL((cgm_update_kernel<M, U>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st)
+      if (unroll == 1) { if (mode == 0) BP5_UPD(0, 1); else if (mode == 1) BP5_UPD(1, 1); else BP5_UPD(2, 1); }
+      else if (unroll == 4) { if (mode == 0) BP5_UPD(0, 4); else if (mode == 1) BP5_UPD(1, 4); else BP5_UPD(2, 4); }
+      else { if (mode == 0) BP5_UPD(0, 2); else if (mode == 1) BP5_UPD(1, 2); else BP5_UPD(2, 2); }
+#undef BP5_UPD
+    };
     // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
     bool &fused = fused_dots;
     if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty() && overlap_wanted(mf)) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
@@ -1341,9 +1352,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     }
     int it = 1;
     for (; it <= prm->max_iter; ++it) {
-      if (it == 1) hipLaunchKernelGGL(cgm_update_kernel<0>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-      else if (it % 2 == 0) hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-      else hipLaunchKernelGGL(cgm_update_kernel<2>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      launch_update(it == 1 ? 0 : it % 2 == 0 ? 1 : 2);
       KERNEL_CHECK();
       if (fused) {
         uint32_t n_cols = 0;
@@ -1366,7 +1375,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     // epilogue x update (solver.h:510-526) runs inside the next update kernel; with max_iter == 0 no
     // iteration has been done and nothing is pending
     if (prm->max_iter > 0) {
-      hipLaunchKernelGGL(cgm_update_kernel<1>, dim3(grid2), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+      launch_update(1);
       hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
       KERNEL_CHECK();
     }

@@ -2600,7 +2600,7 @@ __device__ __forceinline__ void cgm_update_one(double &p, double &r, const doubl
     p = beta * p - di * rn;
   }
 }
-template <int MODE>
+template <int MODE, int U = 2>
 __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, const double *v, double *x, const double *diag, size_t n,
                                                        const double *sc, const int *st)
 {
@@ -2610,25 +2610,43 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, co
   const double aob = (MODE == 2 || done) ? sc[SC_ALPHA_OLD] / sc[SC_BETA_OLD] : 0.0;
   const bool epi_odd = done && (st[ST_ITER] & 1);
   const bool touch_x = done || MODE == 2, touch_rp = !done;
-  const size_t stride = (size_t)gridDim.x * VB * 2;
-  for (size_t i = ((size_t)blockIdx.x * VB + threadIdx.x) * 2; i < n; i += stride) {
-    if (i + 1 < n) {
-      double2 pv = *reinterpret_cast<double2 *>(p + i), rv = *reinterpret_cast<double2 *>(r + i);
-      double2 vv = (MODE != 0 && !done) ? *reinterpret_cast<const double2 *>(v + i) : double2{0, 0};
-      double2 xv = touch_x ? *reinterpret_cast<double2 *>(x + i) : double2{0, 0};
-      const double d0 = diag ? diag[i] : 1.0, d1 = diag ? diag[i + 1] : 1.0;
-      cgm_update_one<MODE>(pv.x, rv.x, vv.x, xv.x, d0, done, epi_odd, alpha, beta, aob);
-      cgm_update_one<MODE>(pv.y, rv.y, vv.y, xv.y, d1, done, epi_odd, alpha, beta, aob);
-      if (touch_rp) {
-        *reinterpret_cast<double2 *>(p + i) = pv;
-        if (MODE != 0) *reinterpret_cast<double2 *>(r + i) = rv;
+  // U chunks of VB pairs per loop trip: all loads of a trip are issued before its first store (3-4 streams x U 16-byte loads in flight)
+  const size_t stride = (size_t)gridDim.x * VB * 2 * U;
+  for (size_t base = ((size_t)blockIdx.x * VB * U + threadIdx.x) * 2; base < n; base += stride) {
+    double2 pv[U], rv[U], vv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + (size_t)u * VB * 2;
+      pv[u] = rv[u] = vv[u] = xv[u] = double2{0, 0};
+      if (i + 1 < n) {
+        pv[u] = *reinterpret_cast<double2 *>(p + i);
+        rv[u] = *reinterpret_cast<double2 *>(r + i);
+        if (MODE != 0 && !done) vv[u] = *reinterpret_cast<const double2 *>(v + i);
+        if (touch_x) xv[u] = *reinterpret_cast<double2 *>(x + i);
+      } else if (i < n) {
+        pv[u].x = p[i]; rv[u].x = r[i];
+        if (MODE != 0 && !done) vv[u].x = v[i];
+        if (touch_x) xv[u].x = x[i];
       }
-      if (touch_x) *reinterpret_cast<double2 *>(x + i) = xv;
-    } else {
-      double pi = p[i], ri = r[i], xi = x[i];
-      cgm_update_one<MODE>(pi, ri, (MODE != 0 && !done) ? v[i] : 0.0, xi, diag ? diag[i] : 1.0, done, epi_odd, alpha, beta, aob);
-      if (touch_rp) { p[i] = pi; if (MODE != 0) r[i] = ri; }
-      if (touch_x) x[i] = xi;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + (size_t)u * VB * 2;
+      if (i >= n) continue;
+      const bool pair = i + 1 < n;
+      const double d0 = diag ? diag[i] : 1.0, d1 = (diag && pair) ? diag[i + 1] : 1.0;
+      cgm_update_one<MODE>(pv[u].x, rv[u].x, vv[u].x, xv[u].x, d0, done, epi_odd, alpha, beta, aob);
+      if (pair) cgm_update_one<MODE>(pv[u].y, rv[u].y, vv[u].y, xv[u].y, d1, done, epi_odd, alpha, beta, aob);
+      if (pair) {
+        if (touch_rp) {
+          *reinterpret_cast<double2 *>(p + i) = pv[u];
+          if (MODE != 0) *reinterpret_cast<double2 *>(r + i) = rv[u];
+        }
+        if (touch_x) *reinterpret_cast<double2 *>(x + i) = xv[u];
+      } else {
+        if (touch_rp) { p[i] = pv[u].x; if (MODE != 0) r[i] = rv[u].x; }
+        if (touch_x) x[i] = xv[u].x;
+      }
     }
   }
 }
