@@ -573,7 +573,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
   if (mf->has_hanging) return 90;
   const int v = mf->apply_variant;
   if (v != 0) return v;
-  if (mf->degree == 1 || (mf->degree == 3 && mf->h_block_off.empty())) {
+  if ((mf->degree == 1 || mf->degree == 3) && mf->h_block_off.empty()) {
     if (mf->geometry_mode == BP5_GEOM_AFFINE) return 0;
     if (mf->auto_team < 0) { // an irregular cell order can exhaust the team plan's rounds: then the atomic pencil kernel
       bp5_mf::DevPlan *dp = nullptr;
@@ -582,7 +582,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     return mf->auto_team ? 10 : 0;
   }
   if (!block_lpc(mf->degree)) return 0;
-  const int fallback = (mf->degree == 4 && mf->geometry_mode == BP5_GEOM_AFFINE) ? 10 : mf->degree == 3 ? 10 : 0; // else the pencil kernel
+  const int fallback = (mf->degree == 4 && mf->geometry_mode == BP5_GEOM_AFFINE) ? 10 : (mf->degree == 3 || mf->degree == 1) ? 10 : 0; // else the pencil kernel
   if (mf->degree != 4 && mf->geometry_mode == BP5_GEOM_AFFINE) return 0; // the affine block build exists at p = 4 only
   uint32_t b0_, b1_;
   if (mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &b0_, &b1_)) return fallback;
@@ -593,7 +593,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
       // LDS of the default shape: one transpose tile per cell slot + the brick's accumulator + two run tables; p <= 4 must fit
       // three workgroups per CU, p >= 5 (more registers per lane: two workgroups per CU anyway) two
       const int n = mf->degree + 1, ps = mf->degree == 4 ? LdsLayout<5, 32>::PS : mf->degree == 6 ? LdsLayout<7, 64>::PS : mf->degree == 5 ? LdsLayout<6, 64>::PS :
-                                         mf->degree == 7 ? LdsLayout<8, 64>::PS : mf->degree == 3 ? LdsLayout<4, 16>::PS : LdsLayout<3, 16>::PS;
+                                         mf->degree == 7 ? LdsLayout<8, 64>::PS : mf->degree == 3 ? LdsLayout<4, 16>::PS : mf->degree == 1 ? LdsLayout<2, 4>::PS : LdsLayout<3, 16>::PS;
       const size_t lds = ((size_t)block_cpt(mf) * (n * ps + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
       mf->auto_block = lds * (mf->degree <= 4 ? 3 : 2) <= 160 * 1024 && (mf->degree == 4 || dp->packed);
       // persistent workgroups need enough bricks each to balance: round 1 measured 3.6 bricks per workgroup (54^3 cells)
