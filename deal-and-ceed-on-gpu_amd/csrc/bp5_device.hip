@@ -593,7 +593,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
       // LDS of the default shape: one transpose tile per cell slot + the brick's accumulator + two run tables; p <= 4 must fit
       // three workgroups per CU, p >= 5 (more registers per lane: two workgroups per CU anyway) two
       const int n = mf->degree + 1, ps = mf->degree == 4 ? LdsLayout<5, 32>::PS : mf->degree == 6 ? LdsLayout<7, 64>::PS : mf->degree == 5 ? LdsLayout<6, 64>::PS :
-                                         mf->degree == 7 ? LdsLayout<8, 64>::PS : mf->degree == 3 ? LdsLayout<4, 16>::PS : mf->degree == 1 ? LdsLayout<2, 4>::PS : LdsLayout<3, 16>::PS;
+                                         mf->degree == 7 ? LdsLayout<8, 64>::PS : mf->degree == 8 ? LdsLayout<9, 128>::PS : mf->degree == 3 ? LdsLayout<4, 16>::PS : mf->degree == 1 ? LdsLayout<2, 4>::PS : LdsLayout<3, 16>::PS;
       const size_t lds = ((size_t)block_cpt(mf) * (n * ps + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
       mf->auto_block = lds * (mf->degree <= 4 ? 3 : 2) <= 160 * 1024 && (mf->degree == 4 || dp->packed);
       // persistent workgroups need enough bricks each to balance: round 1 measured 3.6 bricks per workgroup (54^3 cells)

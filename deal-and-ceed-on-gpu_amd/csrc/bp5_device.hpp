@@ -130,7 +130,7 @@ struct bp5_mf {
 // Lanes per cell of the block-assembled kernel's default shape (one transpose tile per cell used field after field: the lanes
 // of a cell must sit in one wave, so LPC divides 64).  0 = the degree has no such shape (p = 8: 81
 // lanes per cell do not fit a wave, atomic pencil kernel).  Cells per pass = 256 / LPC.
-constexpr int block_lpc(int degree) { return degree == 1 ? 4 : degree == 2 || degree == 3 ? 16 : degree == 4 ? 32 : degree >= 5 && degree <= 7 ? 64 : 0; }
+constexpr int block_lpc(int degree) { return degree == 1 ? 4 : degree == 2 || degree == 3 ? 16 : degree == 4 ? 32 : degree >= 5 && degree <= 7 ? 64 : degree == 8 ? 128 : 0; }
 inline int block_cpt(const bp5_mf *mf) { return block_lpc(mf->degree) ? 256 / block_lpc(mf->degree) : 8; }
 
 template <typename T>

@@ -1145,7 +1145,7 @@ struct BlockPass {
   static constexpr bool STAGE = (ABL & 524288) != 0;
   static_assert(!STAGE || (PACK && (ABL & 16384)), "LDS-staged src needs packed indices and the run table");
   static constexpr bool SEQ = (ABL & 8192) != 0;
-  static_assert(!SEQ || WAVE_LOCAL, "sequential tiles need wave-local cells");
+  // (p = 8: 81 lanes per cell span two waves; the tile exchanges then use the workgroup barrier -- correct, every lane reaches every sync)
   static constexpr int TILE_CS = SEQ ? (n * L::PS + 3) : L::CS; // doubles per cell slot
   static __device__ __forceinline__ void tile_sync()
   {

@@ -173,6 +173,36 @@ def _worker(rank, world, port, p, cells, quad, amp, numbering, block, iters, out
             gg = _allreduce(g[:no] @ g[:no])
             beta, gh = gg / gh, gg
             d[:no] = beta * d[:no] - g[:no]
+        # the merged solver's FUSED dot products across ranks (csrc/bp5_device.hip: solver_vmult with fuse_r, unpack_add_dots_kernel):
+        # p.v as the sum over every rank's OWN cells of u_e . (A_e u_e) (no owner bookkeeping), v.v / r.v over owned DoFs formed
+        # from the LOCAL sums first and corrected by the owners for the ghost contributions they add (Dirichlet owners keep v = p)
+        pv_, rv_ = d.copy(), g.copy()
+        _halo_gather(m, pv_)
+        n3 = (p + 1) ** 3
+        idx = m.l2g.astype(np.int64)
+        v_loc = O.apply_cells(lm, coef, N, D, pv_)                       # local sums, ghost entries included
+        ye = np.zeros((m.n_cells, n3))
+        for c0 in range(m.n_cells):                                      # per-cell energies u_e . (A_e u_e)
+            one = np.zeros(m.n_local)
+            one[idx[c0]] = pv_[idx[c0]]
+            ye[c0] = O.apply_cells(lm, coef, N, D, one, cell_range=(c0, c0 + 1))[idx[c0]]
+        energy = float(np.sum(pv_[idx] * ye))
+        con = np.zeros(m.n_local, bool)
+        con[c] = True
+        v_own = np.where(con[:no], pv_[:no], v_loc[:no])                 # write-out: Dirichlet rows store p
+        vv_loc, rv_loc = float(v_own @ v_own), float(rv_[:no] @ v_own)
+        energy += float(np.sum(pv_[:no][con[:no]] * (pv_[:no][con[:no]] - v_loc[:no][con[:no]])))
+        contrib = np.zeros(m.n_local)
+        contrib[no:] = v_loc[no:]
+        _halo_scatter_add(m, contrib)                                    # owners receive the ghost contributions
+        add = np.where(con[:no], 0.0, contrib[:no])
+        vv_corr = float(np.sum((v_own + add) ** 2 - v_own ** 2))
+        rv_corr = float(rv_[:no] @ add)
+        fused = _allreduce([energy, vv_loc + vv_corr, rv_loc + rv_corr])
+        pv_[no:] = 0.0
+        h_ref = vmult(d.copy())                                          # the assembled, exchanged product
+        plain = _allreduce([float(d[:no] @ h_ref[:no]), float(h_ref[:no] @ h_ref[:no]), float(g[:no] @ h_ref[:no])])
+        assert np.allclose(fused, plain, rtol=1e-12, atol=1e-14 * abs(plain[1])), (fused, plain)
         # one more vmult of a deterministic vector with non-zero boundary values
         s_lex = O.deterministic_src(int(m.n_global_dofs), seed=21)
         src = np.zeros(m.n_local)

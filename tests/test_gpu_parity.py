@@ -322,10 +322,10 @@ def test_default_block_kernel_on_other_brick_shapes(block, cells, numbering, ord
 
 
 @pytest.mark.parametrize("p,cells,block", [(1, (17, 9, 10), (8, 8, 8)), (2, (9, 8, 5), (8, 8, 4)), (3, (9, 5, 6), (8, 4, 4)), (3, (5, 5, 5), (4, 4, 4)), (5, (5, 6, 3), (4, 4, 2)),
-                                           (6, (5, 4, 3), (4, 4, 2)), (6, (4, 3, 3), (4, 2, 2)), (7, (5, 3, 3), (4, 2, 2))])
+                                           (6, (5, 4, 3), (4, 4, 2)), (6, (4, 3, 3), (4, 2, 2)), (7, (5, 3, 3), (4, 2, 2)), (8, (3, 3, 3), (2, 2, 2))])
 @pytest.mark.parametrize("quad", [0, 1])
 def test_deterministic_block_kernel_for_the_other_degrees(p, cells, block, quad):
-    """The non-atomic default shape (sequential tiles, run-length write-out, packed indices: variant 56) on p = 1, 2, 3, 5, 6, 7 --
+    """The non-atomic default shape (sequential tiles, run-length write-out, packed indices: variant 56) on p = 1, 2, 3, 5, 6, 7, 8 --
     the reference's scatter is an FP64 atomicAdd (bp5/fe_evaluation_gl.h:176-180: non-deterministic).  Bricks with partial
     ones at the mesh edge, several bricks per persistent workgroup, deformed cells, variable coefficient: equal to the oracle,
     bitwise reproducible; and the merged CG with the dot products fused into it matches the oracle's plain CG."""
