@@ -212,6 +212,17 @@ def main():
         sustained = {"value": best, "unit": "DoF/s", "iterations": args.sustained_iters, "repetitions": args.sustained_reps,
                      "protocol": "reference: best of n repetitions of one solve, wall clock incl. device sync (bp5/step-64.cu:457-463,724-730)"}
 
+    # the bare operator kernel in the same run (when the timed solve fused the dot products into it): a short solve with the
+    # separate dot-product kernel, so that the operator-only roofline figure of SURVEY 8(d) can be read off the same box
+    unfused_ms = None
+    if ctl.dot_products_fused:
+        op.mf_data.set_cg_fusion(False)
+        uctl = pkg.IterationNumberControl(10, 0.0)
+        Solver(uctl, profile=True).solve(op, x, b, precond)
+        barrier()
+        unfused_ms = uctl.apply_ms_avg
+        op.mf_data.set_cg_fusion(True)
+
     # achievable-stream figure: device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
     import ctypes as C
     ya, xa = op.initialize_dof_vector(), op.initialize_dof_vector()
@@ -275,6 +286,10 @@ def main():
                          "bytes_per_dof": B_kernel, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
                          "operator_ms": ctl.operator_ms_avg,
                          "frac_operator_only": B_op * n_dofs_local / apply_s / 1e9 / HBM_PEAK_GBS if apply_s > 0 else 0.0,
+                         # the same operator kernel WITHOUT the fused dot products (10 untimed iterations after the timed region): the
+                         # SURVEY 8(d) operator-only figure, B_op x DoFs / its average launch duration
+                         "operator_kernel_unfused": ({"avg_launch_ms": unfused_ms, "bytes_per_dof": B_op,
+                                                      "frac": B_op * n_dofs_local / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if unfused_ms else None),
                          "algorithmic_formula": (f"16 + I*4r + G*8r" + (" + 24 [fused dot products: p, r, v]" if fused else "") +
                                                  f" B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)"),
                          # what this kernel has to move for its own representation (the contract formula credits I = 1 and 24 B for the dots)
