@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of operator-kernel variants in ONE process, interleaved rounds (guide rule 24).
-usage: python tools/bench_apply.py --degree 4 --cells 116 116 116 --variants 0 1 2 3 4 5"""
+usage: python tools/bench_apply.py --degree 4 --cells 116 116 116 --variants 0 1 2 3 4 5
+The timing-only ablation variants (wrong results by construction: 20+mask, 40+mask, 60+mask, 80-99, ...) exist only in the separate
+library: `make -C deal-and-ceed-on-gpu_amd/csrc timing` and run with BP5_LIB=deal-and-ceed-on-gpu_amd/libbp5_timing.so."""
 import argparse, os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
