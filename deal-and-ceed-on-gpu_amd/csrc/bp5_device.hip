@@ -59,6 +59,12 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   mf->n_cells = d->n_cells; mf->n_interior = d->n_interior_cells; mf->n_owned = d->n_owned; mf->n_ghost = d->n_ghost;
   mf->n_constrained = d->n_constrained;
   mf->tab = tab; mf->tab_gauss = tabg;
+  { // metric layout (A/B knob: BP5_COEF_LAYOUT = plane | cell)
+    const char *e = getenv("BP5_COEF_LAYOUT");
+    const bool cell_major = e && !strcmp(e, "cell");
+    mf->coef_plane_stride = cell_major ? (uint64_t)mf->n3 : (uint64_t)mf->n_cells * mf->n3;
+    mf->coef_cell_stride = cell_major ? (uint64_t)6 * mf->n3 : (uint64_t)mf->n3;
+  }
   // validate indices on the host: a bad index would fault on the GPU
   const size_t nl = (size_t)d->n_cells * mf->n3, nloc = mf->n_local();
   for (size_t s = 0; s < nl; ++s)
@@ -317,7 +323,7 @@ extern "C" int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef)
   HIP_TRY(hipSetDevice(mf->device));
   GeomOut o{};
   o.coef = coef;
-  o.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  o.plane_stride = mf->coef_plane_stride; o.cell_stride = mf->coef_cell_stride;
   DISPATCH_N(launch_geometry, mf, o);
 }
 
@@ -325,7 +331,8 @@ template <int n>
 static int launch_permute(bp5_mf *mf, const double *in, double *out)
 {
   const uint64_t total = (uint64_t)6 * mf->n_cells * mf->n3;
-  hipLaunchKernelGGL(metric_permute_kernel<n>, dim3(2048), dim3(256), 0, mf->stream, in, out, total);
+  hipLaunchKernelGGL(metric_permute_kernel<n>, dim3(2048), dim3(256), 0, mf->stream, in, out, total, (uint64_t)mf->n_cells, mf->coef_plane_stride,
+                     mf->coef_cell_stride);
   KERNEL_CHECK();
   return BP5_OK;
 }
@@ -705,7 +712,7 @@ static int launch_diagonal(bp5_mf *mf, const double *coef, double *diag)
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(mf->n_cells, 1), 65536u);
   const bool affine = mf->geometry_mode == BP5_GEOM_AFFINE;
   hipLaunchKernelGGL(diagonal_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, affine ? mf->d_scalar_plane : coef,
-                     (uint64_t)mf->n_cells * mf->n3, affine ? mf->d_gcell : (const double *)nullptr, mf->d_tab, mf->n_cells, diag);
+                     affine ? (uint64_t)mf->n_cells * mf->n3 : mf->coef_plane_stride, mf->coef_cell_stride, affine ? mf->d_gcell : (const double *)nullptr, mf->d_tab, mf->n_cells, diag);
   KERNEL_CHECK();
   return BP5_OK;
 }

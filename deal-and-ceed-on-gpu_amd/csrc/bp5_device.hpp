@@ -66,6 +66,8 @@ struct bp5_mf {
   // Data mirror (lazy)
   uint32_t *d_l2g_padded = nullptr, *d_constraint_mask = nullptr;
   // hanging nodes (2:1 refinement): per-cell masks and the two 1-D interpolation matrices [2][n*n]; has_hanging: some mask != 0
+  // layout of the six metric planes: plane-major [c][cell][q] (round 1) or cell-major [cell][c][q] (one contiguous 48 n^3-byte chunk per cell)
+  uint64_t coef_plane_stride = 0, coef_cell_stride = 0;
   bool has_hanging = false;
   uint32_t *d_hang_mask = nullptr;
   double *d_hang_I = nullptr;
@@ -159,7 +161,7 @@ inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   using L = LdsLayout<n, LPC>;
   ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.plane_stride = mf->coef_plane_stride; a.cell_stride = (ABL & 1024) ? (uint64_t)mf->n3 : mf->coef_cell_stride; // (affine builds read ONE scalar plane)
   a.cell_begin = c0; a.cell_end = c1;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   a.hang_mask = mf->d_hang_mask; a.hang_I = mf->d_hang_I;
@@ -244,7 +246,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   }
   ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.plane_stride = mf->coef_plane_stride; a.cell_stride = (ABL & 1024) ? (uint64_t)mf->n3 : mf->coef_cell_stride; // (affine builds read ONE scalar plane)
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   ShapeArg<n> sh;
@@ -314,7 +316,7 @@ inline int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
   BP5_TRY(get_plan(mf, CPT, tp, &dp));
   ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.plane_stride = mf->coef_plane_stride; a.cell_stride = (OPT & 1024) ? (uint64_t)mf->n3 : mf->coef_cell_stride; // (affine builds read ONE scalar plane)
   a.cell_begin = c0; a.cell_end = c1;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   a.n_teams = (c1 + CPT - 1) / CPT - c0 / CPT;
@@ -366,7 +368,7 @@ inline int launch_march_t(bp5_mf *mf, const double *coef, const double *src, dou
   mp.teams_per_xcd = (mp.n_teams + 7) / 8;
   ApplyArgs a{};
   a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst;
-  a.plane_stride = (uint64_t)mf->n_cells * mf->n3;
+  a.plane_stride = mf->coef_plane_stride; a.cell_stride = (ABL & 1024) ? (uint64_t)mf->n3 : mf->coef_cell_stride; // (affine builds read ONE scalar plane)
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = mp.n_teams; a.teams_per_xcd = mp.teams_per_xcd;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   ShapeArg<n> sh;
@@ -650,7 +652,7 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
   BP5_CASE(4, 40 + (M)) {                                                                                         \
     TeamPlan tp; bp5_mf::DevPlan *dp = nullptr;                                                                    \
     BP5_TRY(get_plan(mf, 10, tp, &dp));                                                                            \
-    ApplyArgs a; a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst; a.plane_stride = (uint64_t)mf->n_cells * mf->n3; \
+    ApplyArgs a; a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst; a.plane_stride = mf->coef_plane_stride; a.cell_stride = mf->coef_cell_stride; \
     a.cell_begin = c0; a.cell_end = c1; a.n_teams = (c1 + 9) / 10 - c0 / 10; a.teams_per_xcd = (a.n_teams + 7) / 8;  \
     ShapeArg<5> sh; memcpy(sh.N, mf->tab.N, sizeof(sh.N)); memcpy(sh.D, mf->tab.D, sizeof(sh.D));                  \
     hipLaunchKernelGGL((apply_team_kernel<4, false, 4, 25, true, SC_OWNER_SET, M>), dim3(a.teams_per_xcd * 8), dim3(256), \

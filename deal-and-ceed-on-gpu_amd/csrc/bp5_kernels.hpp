@@ -65,7 +65,8 @@ struct ApplyArgs {
   const double *coef;
   const double *src;
   double *dst;
-  uint64_t plane_stride; // n_cells_total * n^3
+  uint64_t plane_stride; // doubles between two planes of one cell: n_cells_total * n^3 (plane-major) or n^3 (cell-major)
+  uint64_t cell_stride;  // doubles between two cells of one plane: n^3 (plane-major, affine scalar plane) or 6 n^3 (cell-major)
   uint32_t cell_begin, cell_end;
   uint32_t n_teams;      // teams needed for the range
   uint32_t teams_per_xcd;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     }
   }
   // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
-  const double *cf = a.coef + cell * n3; // cell base; lane offsets through coef_off / load_pencil
+  const double *cf = a.coef + cell * a.cell_stride; // cell base; lane offsets through coef_off / load_pencil
   constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
   double S[(PF && !AFFINE) ? 6 : 1][n];
   double Gc[6] = {0, 0, 0, 0, 0, 0};
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(64 * TW) apply_march_kernel(ApplyArgs a, March
     }
 
     // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
-    const double *cf = a.coef + cell * n3; // cell base; lane offsets through coef_off / load_pencil
+    const double *cf = a.coef + cell * a.cell_stride; // cell base; lane offsets through coef_off / load_pencil
     constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
     double S[(PF && !AFFINE) ? 6 : 1][n];
     double Gc[6] = {0, 0, 0, 0, 0, 0};
@@ -812,7 +813,7 @@ __global__ void __launch_bounds__(64 * TW) apply_team_kernel(ApplyArgs a, TeamPl
   const int my_round = tp.cell_round[cell];
   const int n_rounds = tp.team_rounds[team];
   // ---- metric planes (issued early; consumed after the evaluate phase)
-  const double *cf = a.coef + cell * n3; // cell base; lane offsets through coef_off / load_pencil
+  const double *cf = a.coef + cell * a.cell_stride; // cell base; lane offsets through coef_off / load_pencil
   constexpr bool AFFINE = (ABL & 1024) != 0;
   double S[(PF && !AFFINE) ? 6 : 1][n];
   double Gc[6] = {0, 0, 0, 0, 0, 0};
@@ -1169,7 +1170,7 @@ struct BlockPass {
   static __device__ __forceinline__ void issue_metric(const ApplyArgs &a, R &r, int abm)
   {
     const uint64_t cell = r.ent & 0x7fffffffu;
-    const double *cf = a.coef + cell * n3; // cell base (pair layout, load_pencil)
+    const double *cf = a.coef + cell * a.cell_stride; // cell base (pair layout, load_pencil)
     if constexpr (AFFINE) {
       load_pencil<n>(cf, abm, r.S[0]);
 #pragma unroll
@@ -2005,7 +2006,7 @@ __device__ void hang_resolve3(uint32_t m, const double *I, double *v, double *t,
 
 struct GeomOut {
   double *coef;          // permuted merged metric or NULL
-  uint64_t plane_stride; // n_cells * n3
+  uint64_t plane_stride, cell_stride; // layout of the six planes (see ApplyArgs)
   double *inv_jac;       // 9 planes of n_cells*pad, or NULL
   double *JxW;           // n_cells*pad or NULL
   double *q_points;      // 3 planes of n_cells*pad or NULL
@@ -2074,7 +2075,7 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
     const double jxw = fabs(det) * w[i] * w[j] * w[k];
     if (o.coef) {
       const double s = jxw * kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
-      double *c = o.coef + cell * n3 + coef_off<n>(i, j + n * k); // pair layout (coef_off)
+      double *c = o.coef + cell * o.cell_stride + coef_off<n>(i, j + n * k); // pair layout (coef_off)
       c[0 * o.plane_stride] = s * (K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2]);
       c[1 * o.plane_stride] = s * (K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2]);
       c[2 * o.plane_stride] = s * (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]);
@@ -2116,14 +2117,15 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
 
 // permute merged metric between the device layout (x slowest) and the reference layout
 template <int n>
-__global__ void metric_permute_kernel(const double *in, double *out, uint64_t total /*6*n_cells*n3*/)
+__global__ void metric_permute_kernel(const double *in, double *out, uint64_t total /*6*n_cells*n3*/, uint64_t n_cells, uint64_t plane_stride,
+                                      uint64_t cell_stride)
 {
   constexpr int n2 = n * n, n3 = n2 * n;
   for (uint64_t o = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; o < total; o += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t cellplane = o / n3;
+    const uint64_t cellplane = o / n3, plane = cellplane / n_cells, cell = cellplane - plane * n_cells; // reference order [c][cell][q]
     const int q = (int)(o - cellplane * n3); // reference index qi + n(qj + n qk)
     const int qi = q % n, rest = q / n;      // rest = qj + n qk
-    out[o] = in[cellplane * n3 + coef_off<n>(qi, rest)];
+    out[o] = in[plane * plane_stride + cell * cell_stride + coef_off<n>(qi, rest)];
   }
 }
 
@@ -2166,7 +2168,7 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
 // one thread per local DoF.  coef: the handle's six planes (device layout, q index = a*n*n + b + n*c), or, in affine
 // mode (gcell != NULL), the scalar plane times the cell's constant K K^T.
 template <int n>
-__global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, const double *gcell,
+__global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, uint64_t cell_stride, const double *gcell,
                                                           const double *tab, uint32_t n_cells, double *diag)
 {
   constexpr int n2 = n * n, n3 = n2 * n;
@@ -2184,7 +2186,7 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
     double acc = 0.0;
     for (int c = 0; c < 6; ++c) {
       // this thread's q-point (a,b,c) = (i,j,k) in the device (pair) layout
-      const uint64_t at = cell * n3 + coef_off<n>(i, j + n * k);
+      const uint64_t at = cell * (gcell ? (uint64_t)n3 : cell_stride) + coef_off<n>(i, j + n * k);
       S[q] = gcell ? coef[at] * gcell[(uint64_t)c * n_cells + cell] : coef[(uint64_t)c * plane_stride + at];
       __syncthreads();
       const double *X = (c == 0) ? DD : (c == 3 || c == 4) ? ND : NN;
