@@ -717,6 +717,21 @@ def test_merged_cg_with_dot_products_fused_into_the_block_kernel(cells, block, w
     assert torch.equal(sols[0], sols[2])                                      # fixed summation order
     assert float((sols[0] - sols[1]).abs().max()) < 1e-12 * float(sols[1].abs().max())
     assert abs(ress[0] - ress[1]) < 1e-10 * ress[1]
+    # right-hand side with NON-zero entries on the Dirichlet rows (inhomogeneous boundary values through b): then p is non-zero there and
+    # the quadrature-point form of p.v needs its Dirichlet correction p (p - sum) -- same iterate as the separate kernels and as the
+    # oracle's MERGED recurrence (A_eff is not symmetric for such vectors, so plain and merged CG are different iterations here)
+    cdofs = torch.from_numpy(mesh.constrained.astype(np.int64)).cuda()
+    bi = b.clone()
+    bi[cdofs] = 0.3 + 0.1 * torch.cos(torch.arange(cdofs.numel(), dtype=torch.float64, device="cuda:0"))
+    bi_lex = np.zeros(pr.mesh.n_dofs)
+    bi_lex[perm] = bi.cpu().numpy()
+    xi_ref, _, _ = O.cg_merged(pr.vmult, bi_lex, 8)
+    for fused in (True, False):
+        op.mf_data.set_cg_fusion(fused)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(8, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, bi, pkg.DiagonalMatrix())
+        assert ctl.dot_products_fused == fused and rel(x.cpu().numpy(), xi_ref[perm]) < TOL_CG
     # tolerance stop (constant coefficient, undeformed: converges in tens of iterations): the device-side convergence flag
     # turns the fused kernels into no-ops at the same iteration, and the recurrence residual is the true one
     op2 = pkg.PoissonOperator(pkg.BrickMesh(p, cells, h=0.125, cell_block=block, dof_numbering=1, cell_block_order=1), 0)

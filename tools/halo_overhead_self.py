@@ -44,9 +44,10 @@ ap.add_argument("--rank", type=int, default=3)
 ap.add_argument("--weak", action="store_true", help="every rank owns 116 cell layers (round-1 weak-scaling shape) instead of 116/ranks")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--solver", choices=["merged", "plain"], default="merged")
+ap.add_argument("--cell-block", type=int, nargs=3, default=[4, 4, 4])
 args = ap.parse_args()
 p, n = 4, 116
-kw = dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+kw = dict(cell_block=tuple(args.cell_block), dof_numbering=1, cell_block_order=1)
 nz = n * args.ranks if args.weak else n
 m1 = pkg.BrickMesh(p, (n, n, nz), h=1.0 / n, rank=args.rank, n_ranks=args.ranks, **kw)
 ng, no = m1.n_ghost, m1.n_owned
@@ -78,6 +79,8 @@ for name in ("slab + exchange, overlapped", "slab + exchange, sequential", "same
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / args.iters * 1e3)
     res[name] = best
+    info = op.mf_data.block_plan_info() if op.mf_data.get_apply_variant() == 56 else None
+    print(f"{name}: plan (bricks, max runs, packed) {info}, dot products fused {ctl.dot_products_fused}")
     print(f"{name}: {best:.3f} ms per iteration ({msh.n_owned / best / 1e6:.2f} GDoF/s), operator {ctl.operator_ms_avg:.3f} ms, "
           f"variant {op.mf_data.get_apply_variant()}, cells {msh.n_cells}, owned {msh.n_owned}, ghosts {msh.n_ghost}", flush=True)
     op.mf_data.close()
