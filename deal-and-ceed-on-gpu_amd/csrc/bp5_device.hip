@@ -1351,12 +1351,21 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     };
     // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
     bool &fused = fused_dots;
-    if (!user && mf->cg_fusion && !diag && !(mf->comm && !mf->neighbors.empty() && overlap_wanted(mf)) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
+    // Across ranks the fused iteration uses the unsplit exchange: it saves a pass over p, r, v (24 B/DoF) where the 3-phase split would
+    // hide one DoF plane each way, so under the automatic overlap policy (2) fusion wins at every slab size; only an explicit
+    // bp5_mf_set_overlap(1) keeps the split schedule (and with it the separate dot-product kernel).
+    const bool dist_solve = mf->comm && !mf->neighbors.empty();
+    if (!user && mf->cg_fusion && !diag && !(dist_solve && mf->overlap == 1) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
         effective_variant(mf, 0, mf->n_cells) == 56) {
       bp5_mf::DevPlan *dp = nullptr;
       BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));
       fused = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);
     }
+    struct OverlapGuard { // the fused exchange stays on the compute stream whatever the slab size
+      bp5_mf *m; int saved;
+      ~OverlapGuard() { m->overlap = saved; }
+    } overlap_guard{mf, mf->overlap};
+    if (fused && dist_solve) mf->overlap = 0;
     int it = 1;
     for (; it <= prm->max_iter; ++it) {
       launch_update(it == 1 ? 0 : it % 2 == 0 ? 1 : 2);
