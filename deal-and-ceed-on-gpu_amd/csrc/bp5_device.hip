@@ -922,6 +922,7 @@ extern "C" int bp5_mf_set_overlap(bp5_mf *mf, int mode)
 static bool overlap_wanted(const bp5_mf *mf) { return mf->overlap == 1 || (mf->overlap == 2 && mf->n_interior >= 1000000u); }
 // ghost gather: owners send their interface values (packed through send_indices), ghosts are
 // received straight into the vector's ghost range (contiguous per neighbour)
+static int gather_exchange(bp5_mf *mf, double *v, bool on_comm_stream);
 extern "C" int bp5_halo_gather_start(bp5_mf *mf, double *v)
 {
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
@@ -934,7 +935,12 @@ extern "C" int bp5_halo_gather_start(bp5_mf *mf, double *v)
     hipLaunchKernelGGL(pack_kernel, dim3((ns + 255) / 256), dim3(256), 0, mf->stream, mf->d_send_idx, ns, v, mf->d_sendbuf);
     KERNEL_CHECK();
   }
-  mf->overlap_now = overlap_wanted(mf);
+  return gather_exchange(mf, v, overlap_wanted(mf));
+}
+// the RCCL part of the ghost gather: d_sendbuf is packed (on the compute stream); ghosts arrive in v's ghost range
+static int gather_exchange(bp5_mf *mf, double *v, bool on_comm_stream)
+{
+  mf->overlap_now = on_comm_stream;
   hipStream_t cs = mf->overlap_now ? mf->comm_stream : mf->stream;
   if (mf->overlap_now) { // the exchange starts once the values are packed (and everything before them on the compute stream is done)
     HIP_TRY(hipEventRecord(mf->ev_halo[0], mf->stream));
@@ -1195,7 +1201,8 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
     // unsplit exchange + fused dot products: gather, ONE fused launch over all cells (p.v is a sum over cells, so it needs no
     // owner bookkeeping; v.v, r.v, r.r run over owned DoFs), then the ghost contributions travel to their owners, whose
     // unpack kernel corrects v.v and r.v for what it adds
-    BP5_TRY(bp5_halo_gather(mf, src));
+    if (mf->fuse.gather_in_flight) { mf->fuse.gather_in_flight = false; BP5_TRY(bp5_halo_gather_finish(mf, src)); } // started under the update kernel
+    else BP5_TRY(bp5_halo_gather(mf, src));
     BP5_TRY(prof.mark(0));
     BP5_TRY(prof.mark(1));
     if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
@@ -1301,6 +1308,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   HIP_TRY(hipEventRecord(ev0, s));
   const bool plain = prm->variant == BP5_CG_PLAIN;
   bool fused_dots = false;
+  mf->fuse = bp5_mf::Fuse{}; // (nothing of an earlier, failed solve survives)
   const int check = prm->check_every;
   int status = BP5_OK;
 
@@ -1366,9 +1374,27 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
       ~OverlapGuard() { m->overlap = saved; }
     } overlap_guard{mf, mf->overlap};
     if (fused && dist_solve) mf->overlap = 0;
+    // fused iteration across ranks: the values of the NEW p at the DoFs this rank sends are computed into the send buffer first, so the
+    // ghost gather of p runs on the communication stream underneath the update kernel (which touches owned entries only); the operator
+    // then just waits for the event
+    static const bool early_gather_enabled = [] { const char *e = getenv("BP5_EARLY_GATHER"); return !(e && e[0] == '0'); }(); // A/B knob for tools
+    const bool early_gather = fused && dist_solve && early_gather_enabled;
+    auto gather_under_update = [&](int mode) -> int {
+      BP5_TRY(halo_streams(mf));
+      const uint32_t ns = mf->send_off.back();
+      if (ns) {
+        const dim3 gr((ns + 255) / 256), bl(256);
+        if (mode == 0) hipLaunchKernelGGL(cgm_pack_updated_kernel<0>, gr, bl, 0, s, mf->d_send_idx, ns, d, g, h, diag, mf->d_sc, mf->d_st, mf->d_sendbuf);
+        else hipLaunchKernelGGL(cgm_pack_updated_kernel<1>, gr, bl, 0, s, mf->d_send_idx, ns, d, g, h, diag, mf->d_sc, mf->d_st, mf->d_sendbuf);
+        KERNEL_CHECK();
+      }
+      return gather_exchange(mf, d, true);
+    };
     int it = 1;
     for (; it <= prm->max_iter; ++it) {
-      launch_update(it == 1 ? 0 : it % 2 == 0 ? 1 : 2);
+      const int mode = it == 1 ? 0 : it % 2 == 0 ? 1 : 2;
+      if (early_gather) { BP5_TRY(gather_under_update(mode)); mf->fuse.gather_in_flight = true; }
+      launch_update(mode);
       KERNEL_CHECK();
       if (fused) {
         uint32_t n_cols = 0;

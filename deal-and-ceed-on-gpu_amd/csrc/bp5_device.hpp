@@ -121,6 +121,7 @@ struct bp5_mf {
     const double *p = nullptr, *r = nullptr;
     uint32_t n_cols = 0; // columns of d_partials written so far (block kernel workgroups, then the combine pass)
     bool ghosts_zeroed = false; // the exchange's unpack kernel has zeroed the ghost ranges of v and p
+    bool gather_in_flight = false; // the solver started the ghost gather of p under its update kernel
   } fuse;
   std::vector<uint32_t> h_block_off; // caller-provided cell blocks (may be empty)
   struct DevMarch { uint32_t *team_off = nullptr, *entries = nullptr; uint32_t n_teams = 0; };

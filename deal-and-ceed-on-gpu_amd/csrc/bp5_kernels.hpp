@@ -2652,6 +2652,24 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, co
     }
   }
 }
+// The NEW search direction at the interface DoFs a rank has to send, written straight into the send buffer BEFORE the update kernel
+// runs (same arithmetic, cgm_update_one): the ghost exchange of p then travels under the update kernel instead of after it.
+template <int MODE>
+__global__ void __launch_bounds__(256) cgm_pack_updated_kernel(const uint32_t *idx, uint32_t n, const double *p, const double *r, const double *v,
+                                                             const double *diag, const double *sc, const int *st, double *buf)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = idx[i];
+  double pi = p[g];
+  if (!st[ST_DONE]) { // (a stopped solve leaves p alone)
+    double ri = r[g], xi = 0.0;
+    const double vi = MODE != 0 ? v[g] : 0.0;
+    cgm_update_one<MODE>(pi, ri, vi, xi, diag ? diag[g] : 1.0, false, false, sc[SC_ALPHA], sc[SC_BETA], 0.0);
+  }
+  buf[i] = pi;
+}
+
 // update_b (solver.h:142-311): [p.v, v.v, r.v, r.r, r.Dv, v.Dv, r.Dr]
 static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const double *r, const double *v, const double *diag, size_t n,
                                                      const int *st, double *partials)
