@@ -12,7 +12,9 @@
  *   - pointers are DEVICE pointers unless the parameter name ends in `_host`;
  *   - handles are opaque, one per device; calls on one handle are not thread-safe;
  *   - all device work is enqueued on the handle's stream (bp5_mf_set_stream) and is
- *     asynchronous unless stated otherwise; nothing allocates inside the hot loop;
+ *     asynchronous unless stated otherwise; nothing allocates inside the hot loop; the only other
+ *     stream the library uses is the handle's own communication stream (RCCL halo traffic that
+ *     overlaps compute), ordered against the handle's stream by events in both directions;
  *   - FP64 arithmetic, 32-bit DoF indices (types::global_dof_index, bp5/fe_evaluation_gl.h:84);
  *   - vectors are plain arrays of n_owned + n_ghost doubles, owned range first
  *     (LinearAlgebra::distributed::Vector<double, MemorySpace::CUDA>, bp5/step-64.cu:321-323).
@@ -295,11 +297,12 @@ int bp5_halo_zero_ghosts(bp5_mf *mf, double *v);
  *    slabs of >= 1e6 interior cells, off below: the split costs 50-80 us per application (three launches, four cross-stream
  *    dependencies) and hides one DoF plane each way (profiles/r2 README, p_*) */
 int bp5_mf_set_overlap(bp5_mf *mf, int mode);
-/* distributed vmult == PoissonOperator::vmult on more than one rank (bp5/step-64.cu:263-276 with the cell_loop of :274):
- *    ghost gather started; first part of the interior cells [0, n_interior_cells) underneath it; gather finished; the cells
+/* distributed vmult == PoissonOperator::vmult on more than one rank (bp5/step-64.cu:263-276 with the cell_loop of :274).
+ *    With the overlapped schedule (bp5_mf_set_overlap): ghost gather started; first part of the interior cells [0, n_interior_cells) underneath it; gather finished; the cells
  *    that touch ghosts; ghost contributions sent to their owners (atomic kernels: under the rest of the interior cells; the
  *    block kernel: after its single combine pass, which completes the ghost entries) and added; ghosts of src zeroed;
- *    Dirichlet copy.  Same kernels and, with the block kernel, bitwise the same result as the unsplit application. */
+ *    Dirichlet copy.  Same kernels and, with the block kernel, bitwise the same result as the unsplit application (gather,
+ *    all cells, scatter-add on the handle's stream), which is what runs when the overlap policy says off. */
 int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src, double *dst, int zero_dst);
 
 /* ------------------------------------------------------------------------------------------ */
