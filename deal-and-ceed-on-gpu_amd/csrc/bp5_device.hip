@@ -205,7 +205,7 @@ static bool product_variant(int degree, int v)
   if (v == 56 && block_lpc(degree) != 0) return true;
   switch (degree) {
     case 1: case 3: return v == 1;
-    case 4: return (v >= 1 && v <= 6) || (v >= 11 && v <= 14) || (v >= 48 && v <= 61) || v == 71 || v == 72;
+    case 4: return (v >= 1 && v <= 6) || (v >= 11 && v <= 14) || (v >= 48 && v <= 62) || v == 71 || v == 72;
     case 5: return v >= 1 && v <= 3;
     case 6: return v >= 1 && v <= 5;
     case 7: case 8: return (v >= 1 && v <= 3) || v == 5;
@@ -625,7 +625,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 static bool variant_overwrites(const bp5_mf *mf, int ev)
 {
   const int v = ev % 100;
-  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 61)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 62)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
 }
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
@@ -1044,7 +1044,7 @@ static int phases_begin(bp5_mf *mf, double *dst, bool overwrite, ApplyPhases &ph
 {
   ph.user_variant = mf->apply_variant;
   const int ev = effective_variant(mf, 0, mf->n_cells);
-  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61) && block_lpc(mf->degree) != 0 && (mf->degree == 4 || ev % 100 == 56);
+  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61 || ev % 100 == 62) && block_lpc(mf->degree) != 0 && (mf->degree == 4 || ev % 100 == 56);
   ph.overwrite = false;
   if (ph.block) {
     BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &ph.dp));

@@ -589,7 +589,8 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
     // 49 = 56 with run-length write-out but without packed indices (A/B)
     // 60 = 56 with the brick's src staged once in LDS (cells gather from LDS; needs the packed indices)
     // 61 = 56 with non-temporal metric loads (A/B: the once-read metric stream then evicts less of a brick's src from L2)
-    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56 || variant == 60 || variant == 61) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
+    // 62 = 56 with ds_add_f64 for the accumulation into the LDS vector (A/B)
+    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56 || variant == 60 || variant == 61 || variant == 62) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
         struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
         mf->combine_csr = variant == 48;
         bp5_mf::DevPlan *dp_ = nullptr;
@@ -598,6 +599,11 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
           if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 60 needs packed indices (<= 128 runs per cell block)");
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 524288>(mf, coef, src, dst, overwrite);
+        }
+        if (variant == 62) {
+          if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 62 needs packed indices (<= 128 runs per cell block)");
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 4194304>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 4194304>(mf, coef, src, dst, overwrite);
         }
         if (variant == 61) {
           if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 61 needs packed indices (<= 128 runs per cell block)");

@@ -1420,7 +1420,10 @@ struct BlockPass {
         __syncthreads();
         if (act && cur.round == rd) {
 #pragma unroll
-          for (int k = 0; k < n; ++k) acc[cur.ps[k]] += yy[k];
+          for (int k = 0; k < n; ++k) {
+            if constexpr ((ABL & 4194304) != 0) lds_add_f64(acc + cur.ps[k], yy[k]); // ds_add_f64, no return value: one LDS op per entry
+            else acc[cur.ps[k]] += yy[k];
+          }
         }
       }
       BP5_STAMP(5)
