@@ -216,3 +216,20 @@ def test_bench_launches_its_own_ranks_and_strong_scales_by_default():
         assert sum(d["n_owned"] for d in parts) == n_global                  # every DoF owned exactly once
         assert sum(d["n_cells"] for d in parts) == 8 * 8 * (10 if mode == "strong" else 20)
         assert parts[0]["neighbors"] == [1] and parts[1]["neighbors"] == [0] and parts[1]["n_ghost"] == 33 * 33
+
+
+def test_round2_entry_points_validate_their_arguments_without_a_gpu():
+    """The entry points added in round 2 reject NULL handles / callbacks before anything touches a device (status codes, no crash)."""
+    L = pkg.lib()
+    null = C.c_void_p()
+    from deal_and_ceed_on_gpu_amd import _lib
+    assert L.bp5_cg_solve_operator(null, _lib.VMULT_FN(0), None, None, None, None, None, None) == 1     # NULL callback
+    for fn in (L.bp5_halo_gather_start, L.bp5_halo_gather_finish, L.bp5_halo_scatter_add_start, L.bp5_halo_scatter_add_finish):
+        assert fn(null, null) == 1
+    assert L.bp5_mf_set_overlap(null, 1) == 1 and L.bp5_mf_set_cg_fusion(null, 1) == 1
+    assert b"null" in L.bp5_last_error().lower() or b"bad" in L.bp5_last_error().lower()
+    # the hanging-node mask bits are part of the ABI (include/bp5.h BP5_HANG_*): the oracle uses the same values
+    assert (O.HANG_FACE, O.HANG_SIDE, O.HANG_HALF) == ((1, 2, 4), (8, 16, 32), (64, 128, 256))
+    text = open(os.path.join(bp5_pkg.ROOT, "include", "bp5.h")).read()
+    for name, val in (("BP5_HANG_FACE_X", 1), ("BP5_HANG_FACE_Z", 4), ("BP5_HANG_SIDE_X", 8), ("BP5_HANG_HALF_X", 64), ("BP5_HANG_HALF_Z", 256)):
+        assert f"{name} = {val}" in text
