@@ -498,11 +498,11 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       }
       start.push_back((uint32_t)ns);
       soff.push_back((uint32_t)slots.size());
-      const size_t n_tiles = (ns + 255) / 256;
+      const size_t n_tiles = (ns + COMBINE_TILE - 1) / COMBINE_TILE;
       tile.resize(n_tiles + 1);
       size_t r = 0;
-      for (size_t t = 0; t <= n_tiles; ++t) { // run containing ordinal min(256 t, ns - 1)
-        const size_t i = std::min(t * 256, ns - 1);
+      for (size_t t = 0; t <= n_tiles; ++t) { // run containing ordinal min(COMBINE_TILE t, ns - 1)
+        const size_t i = std::min(t * (size_t)COMBINE_TILE, ns - 1);
         while (start[r + 1] <= i) ++r;
         tile[t] = (uint32_t)r;
       }
@@ -536,22 +536,22 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
   if (!dp->n_shared) return BP5_OK;
   if (mf->fuse.on && !(set && dp->cr_tile && !mf->combine_csr)) return fail(BP5_ERR_INVALID, "fused dot products need the run-length combine pass in overwrite mode");
   if (mf->prof_mark) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
-  const dim3 cg((dp->n_shared + 255) / 256);
+  const dim3 cg((dp->n_shared + 255) / 256), cgt((dp->n_shared + COMBINE_TILE - 1) / COMBINE_TILE); // CSR kernel / run kernel (pairs)
   if (dp->cr_tile && !mf->combine_csr) {
     CombineRuns cr{};
     cr.start = dp->cr_start; cr.dof0 = dp->cr_dof0; cr.soff = dp->cr_soff; cr.slots = dp->cr_slots; cr.tile_run = dp->cr_tile;
     cr.n_shared = dp->n_shared;
     if (mf->fuse.on) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
-      cr.n_owned = mf->n_owned; cr.n_tiles = cg.x; cr.cg_state = mf->d_st;
-      const uint32_t grid = std::min<uint32_t>(cg.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u); // 1024 columns stay free for the exchange
+      cr.n_owned = mf->n_owned; cr.n_tiles = cgt.x; cr.cg_state = mf->d_st;
+      const uint32_t grid = std::min<uint32_t>(cgt.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u); // 1024 columns stay free for the exchange
       hipLaunchKernelGGL((combine_runs_kernel<false, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
       mf->fuse.n_cols += grid;
       return BP5_OK;
     }
-    if (set) hipLaunchKernelGGL(combine_runs_kernel<false>, cg, dim3(256), 0, mf->stream, cr, dp->partial, dst);
-    else hipLaunchKernelGGL(combine_runs_kernel<true>, cg, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    if (set) hipLaunchKernelGGL(combine_runs_kernel<false>, cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    else hipLaunchKernelGGL(combine_runs_kernel<true>, cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     KERNEL_CHECK();
     return BP5_OK;
   }

@@ -2275,40 +2275,19 @@ struct CombineRuns {
   uint32_t dot_col0, n_owned, n_tiles;
   const int *cg_state;
 };
+constexpr int COMBINE_TILE = 512; // shared-DoF ordinals per tile: 256 threads x one PAIR of consecutive ordinals
 template <bool ADD, bool DOTS = false>
-static __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const double *partial, double *dst)
+__global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const double *partial, double *dst)
 {
-  __shared__ uint32_t s_start[258], s_dof0[257], s_soff[258];
+  __shared__ uint32_t s_start[COMBINE_TILE + 2], s_dof0[COMBINE_TILE + 1], s_soff[COMBINE_TILE + 2];
   __shared__ double s_red[4][4];
   double ds[4] = {0.0, 0.0, 0.0, 0.0};
   if constexpr (DOTS) { if (cr.cg_state[0]) return; }
-  for (uint32_t tile = blockIdx.x; tile < (DOTS ? cr.n_tiles : blockIdx.x + 1); tile += gridDim.x) {
-    if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
-    const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= 256
-    const uint32_t cnt = r_hi - r_lo + 1;
-    for (uint32_t j = threadIdx.x; j <= cnt; j += 256) {
-      s_start[j] = cr.start[r_lo + j];
-      s_soff[j] = cr.soff[r_lo + j];
-      if (j < cnt) s_dof0[j] = cr.dof0[r_lo + j];
-    }
-    __syncthreads();
-    const uint32_t i = tile * 256u + threadIdx.x;
-    if (i >= cr.n_shared) continue;
-    uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_start[mid] <= i) lo = mid; else hi = mid;
-    }
-    const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
-    double s = 0.0; // (a DoF no cell touches has no slot: its sum is zero)
-    if (b < e) {
-      s = partial[cr.slots[b] + j];
-      for (uint32_t q = b + 1; q < e; ++q) s += partial[cr.slots[q] + j];
-    }
-    const uint32_t g = (s_dof0[lo] & 0x7fffffffu) + j;
+  // one value: sum of its partials in ascending group order; Dirichlet rows of the fused build store p instead; dot products
+  auto finish = [&](uint32_t g, bool dirichlet, double s) {
     if constexpr (DOTS) {
       double vi = s;
-      if (s_dof0[lo] & 0x80000000u) { // Dirichlet row: v = p (copy_constrained_values, bp5/step-64.cu:275); p.v correction as in the block kernel
+      if (dirichlet) { // v = p (copy_constrained_values, bp5/step-64.cu:275); p.v correction as in the block kernel
         vi = cr.cg_p[g];
         if (g < cr.n_owned) ds[0] += vi * (vi - s);
       }
@@ -2319,6 +2298,56 @@ static __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr
       }
     } else if (ADD) dst[g] += s;
     else dst[g] = s;
+  };
+  for (uint32_t tile = blockIdx.x; tile < (DOTS ? cr.n_tiles : blockIdx.x + 1); tile += gridDim.x) {
+    if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
+    const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= COMBINE_TILE
+    const uint32_t cnt = r_hi - r_lo + 1;
+    for (uint32_t j = threadIdx.x; j <= cnt; j += 256) {
+      s_start[j] = cr.start[r_lo + j];
+      s_soff[j] = cr.soff[r_lo + j];
+      if (j < cnt) s_dof0[j] = cr.dof0[r_lo + j];
+    }
+    __syncthreads();
+    const uint32_t i = tile * (uint32_t)COMBINE_TILE + 2u * threadIdx.x;
+    if (i >= cr.n_shared) continue;
+    uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_start[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
+    const uint32_t g = (s_dof0[lo] & 0x7fffffffu) + j;
+    const bool dir = (s_dof0[lo] & 0x80000000u) != 0;
+    if (i + 1 < cr.n_shared && i + 1 < s_start[lo + 1]) {
+      // both ordinals in one run: their partials are neighbours in every contributing group's slab range -> 16-byte loads
+      bp5_d2u s2 = bp5_d2u{0.0, 0.0}; // (a DoF no cell touches has no slot: its sum is zero)
+      if (b < e) {
+        s2 = *reinterpret_cast<const bp5_d2u *>(partial + cr.slots[b] + j);
+        for (uint32_t q = b + 1; q < e; ++q) {
+          const bp5_d2u t2 = *reinterpret_cast<const bp5_d2u *>(partial + cr.slots[q] + j);
+          s2.x += t2.x; s2.y += t2.y;
+        }
+      }
+      finish(g, dir, s2.x);
+      finish(g + 1, dir, s2.y);
+    } else {
+      double s = 0.0;
+      if (b < e) {
+        s = partial[cr.slots[b] + j];
+        for (uint32_t q = b + 1; q < e; ++q) s += partial[cr.slots[q] + j];
+      }
+      finish(g, dir, s);
+      if (i + 1 < cr.n_shared) { // first ordinal of the next run
+        const uint32_t l2 = lo + 1, b2 = s_soff[l2], e2 = s_soff[l2 + 1];
+        double s1 = 0.0;
+        if (b2 < e2) {
+          s1 = partial[cr.slots[b2]];
+          for (uint32_t q = b2 + 1; q < e2; ++q) s1 += partial[cr.slots[q]];
+        }
+        finish(s_dof0[l2] & 0x7fffffffu, (s_dof0[l2] & 0x80000000u) != 0, s1);
+      }
+    }
   }
   if constexpr (DOTS) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
