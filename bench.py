@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--sustained-reps", type=int, default=3, help="reference protocol: repetitions, best one reported (bp5/step-64.cu:457-463)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="control-flow rehearsal of an N > 1 run on ONE GPU (tests only): every rank on cuda:0, torch.distributed over gloo, "
+                         "needs BP5_LIB = libbp5_loopback.so (RCCL refuses two ranks on one device); the JSON line is marked, its numbers mean nothing")
     ap.add_argument("--dry-run", action="store_true",
                     help="host only (no GPU, no process group): every rank builds its slab of the mesh and prints its partition as one JSON line")
     args = ap.parse_args()
@@ -119,6 +122,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearsal:
+        if not os.environ.get("BP5_LIB", "").endswith("libbp5_loopback.so"):
+            raise SystemExit("--rehearsal needs BP5_LIB=.../libbp5_loopback.so")
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     comm = None
@@ -128,7 +135,10 @@ def main():
     if world > 1 and not args.dry_run:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
 
     p = args.degree
@@ -178,7 +188,7 @@ def main():
         if world == 1:
             return dt
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearsal else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -298,6 +308,9 @@ def main():
                                                   f"instead of the 4r of local_to_global") if block_kernel else
                                                  f"16 + 4r + G*8r = {B_op:.1f} B/DoF (local_to_global is read)")},
         }
+        if args.rehearsal:
+            out["rehearsal"] = "N ranks on ONE GPU over the loopback transport (tests only): control flow, not a measurement"
+            out["metric"] = "REHEARSAL (not a measurement): " + out["metric"]
         if sustained:
             out["sustained"] = sustained
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only

@@ -1,0 +1,128 @@
+"""N ranks of the library as N PROCESSES ON ONE GPU against the oracle on the undivided mesh.
+
+RCCL refuses two ranks on one device, and the driver's multi-GPU node is not available to the tests: so the library is built a
+second time (libbp5_loopback.so, csrc/Makefile target `loopback`) with its nine RCCL calls renamed to a host-shared-memory
+transport (tests/loopback/loopback_rccl.cpp: stream-ordered, grouped send/recv, rank-ordered all-reduce).  Every other line
+is the product source: z-slab meshes and halo plans of first / middle / last ranks, pack + unpack kernels, gather /
+scatter-add in all three schedules (sequential, 3-phase overlapped, automatic), the block kernel's fused dot products with the
+owners' corrections between DIFFERENT ranks, the 7-value all-reduce of every iteration, compress(add) of the RHS and the
+diagonal, the ghost refresh of the L2 norm.  What this cannot show is xGMI behaviour or RCCL itself (those: the self-neighbour
+tests of test_gpu_parity.py and the driver's scaling run)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bp5_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOOPBACK_LIB = os.path.join(ROOT, "deal-and-ceed-on-gpu_amd", "libbp5_loopback.so")
+WORKER = os.path.join(ROOT, "tests", "loopback", "worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(world, args, out, timeout=420):
+    assert os.path.exists(LOOPBACK_LIB), "libbp5_loopback.so missing: run __graft_entry__.build() (make -C .../csrc loopback)"
+    env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out] + [str(a) for a in args], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs, failed = [], False
+    for r, pr in enumerate(procs):
+        try:
+            o, _ = pr.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:                      # exactly the processes started above
+                q.kill()
+            o, _ = pr.communicate()
+            failed = True
+        logs.append(f"--- rank {r} (exit {pr.returncode}) ---\n{o[-3000:]}")
+        failed = failed or pr.returncode != 0
+    assert not failed, "\n".join(logs)
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("world,p,cells,block,numbering,variant", [
+    (2, 4, (8, 8, 12), (4, 4, 4), 1, 56),  # the bench's configuration: parity-class bricks, block kernel, fused dot products
+    (3, 4, (8, 4, 13), (4, 4, 2), 1, 56),  # first / middle / last rank, ragged slabs (13 layers over 3 ranks), thin bricks
+    (2, 4, (8, 8, 12), (4, 4, 4), 1, 0),   # the library's own choice at this size (too few bricks for the persistent grid: pencil kernel)
+    (3, 2, (3, 3, 7), (0, 0, 0), 0, 0),    # lexicographic cells, atomic pencil kernel
+    (2, 6, (4, 4, 5), (4, 4, 2), 1, 56),   # another degree on the block kernel
+])
+def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells, block, numbering, variant):
+    iters = 8
+    _run_ranks(world, [p, *cells, *block, numbering, iters, variant], str(tmp_path))
+    pr = O.Problem(p, cells, O.QUAD_GAUSS, deform_amp=0.03, kappa=O.kappa_step64)
+    nd = pr.mesh.n_dofs
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    keys = [k for k in ranks[0].files if k[0] in "bAx" or k == "inv_diag"]
+    full = {k: np.full(nd, np.nan) for k in keys}
+    for z in ranks:
+        gid = z["gid"].astype(np.int64)
+        assert np.isnan(full["b"][gid]).all()                            # every DoF owned by exactly one rank
+        for k in keys:
+            full[k][gid] = z[k]
+    assert not any(np.isnan(v).any() for v in full.values())
+    b_ref = pr.rhs()
+    assert _rel(full["b"], b_ref) < 1e-13
+    A_ref = pr.vmult(O.deterministic_src(nd, seed=21))
+    for mode in (0, 1, 2):
+        assert _rel(full[f"A{mode}"], A_ref) < 1e-13, mode
+    x_plain, _, res_plain = O.cg_plain(pr.vmult, b_ref, iters)
+    x_merged, _, res_merged = O.cg_merged(pr.vmult, b_ref, iters)
+    assert _rel(full["x_plain"], x_plain) < 1e-11
+    merged = ["merged_unsplit", "merged_overlapped", "merged_default", "merged_unfused", "merged_unsplit_again"]
+    for k in merged:
+        assert _rel(full["x_" + k], x_merged) < 1e-11, k
+    on_block_kernel = int(ranks[0]["variant"]) == 56
+    assert on_block_kernel == (variant == 56)
+    if on_block_kernel:
+        assert np.array_equal(full["x_merged_unsplit"], full["x_merged_unsplit_again"])     # fixed summation orders: reproducible
+    for z in ranks:
+        assert bool(z["fused_merged_unsplit"]) == on_block_kernel and not bool(z["fused_merged_overlapped"]) and not bool(z["fused_merged_unfused"])
+        assert np.array_equal(z["norms"], ranks[0]["norms"])             # every rank sees the same all-reduced residual
+    assert abs(ranks[0]["norms"][0] - res_plain) < 1e-9 * np.linalg.norm(b_ref)
+    assert abs(ranks[0]["norms"][1] - res_merged) < 1e-9 * np.linalg.norm(b_ref)
+    d_ref = O.operator_diagonal(pr.mesh, pr.coef, pr.N, pr.D)
+    assert _rel(full["inv_diag"], 1.0 / d_ref) < 1e-13
+    x_jac, _, _ = O.cg_merged(pr.vmult, b_ref, iters, diag=1.0 / d_ref)
+    assert _rel(full["x_jacobi"], x_jac) < 1e-11
+    l2 = O.l2_norm_solution(pr.mesh, full["x_merged_default"])
+    for z in ranks:
+        assert abs(float(z["l2"]) - l2) < 1e-12 * l2
+
+
+def test_bench_with_two_ranks_as_the_driver_launches_it():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` (the driver's N > 1 command form):
+    rendezvous, slab meshes, library communicator, barrier + max-over-ranks timing, rank-0 JSON line, teardown.  `--rehearsal`
+    puts both ranks on cuda:0 over the loopback transport; the line is marked as not being a measurement."""
+    import json
+    assert os.path.exists(LOOPBACK_LIB)
+    env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--cells", "16", "16", "16", "--sustained-iters", "0", "--apply-variant", "56", "--rehearsal"]
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "strong" and "rehearsal" in out
+    assert out["config"]["dofs_per_gpu"] < 65 ** 3 and "274625 DoFs" in out["config"]["workload"]      # ONE 16^3-cell problem split over the ranks
+    assert out["config"]["apply_variant"] == 56 and out["config"]["cg_dot_products_fused"] is True      # unsplit exchange, fused dot products
+    assert out["value"] > 0 and "cpu_baseline" not in out

@@ -1136,23 +1136,29 @@ def _consistent_self_glue(m1):
     return send
 
 
-@pytest.mark.parametrize("variant", [56, 3])
-def test_block_kernel_behind_the_halo_exchange(variant):
+@pytest.mark.parametrize("variant,neighbours", [(56, 1), (3, 1), (56, 2)])
+def test_block_kernel_behind_the_halo_exchange(variant, neighbours):
     """The bench's rank-local configuration for ranks > 0 (brick-ordered slab mesh with a ghost plane, block kernel with
     packed indices, overwrite mode) inside bp5_apply_distributed with real RCCL traffic (self neighbour): equals the
-    atomic pencil kernel through the same exchange."""
+    atomic pencil kernel through the same exchange.  neighbours = 2: the neighbour tables of a MIDDLE rank as the mesh
+    generator writes them (rank 1 of 3: ghosts received from the rank below, own top plane sent to the rank above: one
+    receive-only and one send-only neighbour, zero-length messages skipped), both neighbours mapped to the rank itself."""
     from types import SimpleNamespace
     torch = _t()
     import ctypes as C
     p, cells = 4, (9, 8, 10)
-    m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=2, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+    m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=neighbours + 1, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
     ng, no = m1.n_ghost, m1.n_owned
-    send_idx = _consistent_self_glue(m1)
+    if neighbours == 1:
+        tables = dict(n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32),
+                      send_indices=_consistent_self_glue(m1), recv_offsets=np.asarray([0, ng], np.uint32))
+    else:
+        assert m1.n_neighbors == 2 and list(m1.send_offsets) == [0, 0, ng] and list(m1.recv_offsets) == [0, ng, ng]
+        tables = dict(n_neighbors=2, neighbor_rank=np.zeros(2, np.int32), send_offsets=m1.send_offsets, send_indices=m1.send_indices,
+                      recv_offsets=m1.recv_offsets)
     mesh = SimpleNamespace(degree=p, n=p + 1, cells=cells, n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
                            n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
-                           n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32), send_indices=send_idx,
-                           recv_offsets=np.asarray([0, ng], np.uint32), cell_block_offsets=m1.cell_block_offsets, rank=0, n_ranks=1, h=1.0,
-                           deform_amp=0.03)
+                           cell_block_offsets=m1.cell_block_offsets, rank=0, n_ranks=1, h=1.0, deform_amp=0.03, **tables)
     comm = pkg.Communicator(0, 1)
     op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64, comm=comm)
     L, h = pkg.lib(), op.mf_data.handle
