@@ -184,6 +184,12 @@ class BrickMesh:
 HANG_FACE = (1, 2, 4)
 HANG_SIDE = (8, 16, 32)
 HANG_HALF = (64, 128, 256)
+# general 2:1 meshes (cells at edges / corners of a refined region, re-entrant corners): any subset of FACE bits, plus
+#   EDGE_d   the edge along d at the corner (SIDE_e1, SIDE_e2) of the two other directions lies on a coarser cell's edge although
+#            neither face through it is constrained; its n entries name the COARSE edge's DoFs.
+# SIDE_e = HALF_e = the cell's position (0 / 1) inside its parent along e: SIDE_e locates constrained faces / edges, HALF_d picks
+# the half of the coarse entity that the interpolation ALONG d covers.
+HANG_EDGE = (512, 1024, 2048)
 
 
 def hanging_interpolation(p):
@@ -196,9 +202,31 @@ def hanging_interpolation(p):
     return np.stack(out)
 
 
+def hanging_lines(mask, n):
+    """For one cell's mask: per direction d a boolean [k][j][i] array (constant along d) marking the local lines ALONG d whose
+    entries hold coarse values and are interpolated along d with I[HALF_d]: the lines of every constrained face that is
+    tangential to d, and the constrained edge along d.  None where a direction has no such line."""
+    last = n - 1
+    ax = np.arange(n)
+    coord = [ax[None, None, :], ax[None, :, None], ax[:, None, None]]           # direction e lives on array axis 2 - e of [k][j][i]
+    side = [last if (mask & HANG_SIDE[e]) else 0 for e in range(3)]
+    out = []
+    for d in range(3):
+        e1, e2 = [e for e in range(3) if e != d]
+        on = np.zeros((n, n, n), bool)
+        for e in (e1, e2):
+            if mask & HANG_FACE[e]:
+                on |= np.broadcast_to(coord[e] == side[e], (n, n, n))
+        if mask & HANG_EDGE[d]:
+            on |= np.broadcast_to((coord[e1] == side[e1]) & (coord[e2] == side[e2]), (n, n, n))
+        out.append(on if on.any() else None)
+    return out
+
+
 def resolve_hanging(mesh, u, c0=0, c1=None, transpose=False):
-    """In place on u[c0:c1] viewed as [cell][k][j][i][...]: coarse-face values -> fine-face nodal values on every constrained
-    face (transpose: the adjoint, used before the scatter).  Cells without mask bits are untouched."""
+    """In place on u[c0:c1] viewed as [cell][k][j][i][...]: coarse values on constrained faces / edges -> the cell's own nodal
+    values, one 1-D interpolation per direction on the flagged lines (transpose: the adjoint, used before the scatter; the
+    per-direction operators commute).  Cells without mask bits are untouched."""
     mask = getattr(mesh, "constraint_mask", None)
     if mask is None:
         return u
@@ -207,33 +235,19 @@ def resolve_hanging(mesh, u, c0=0, c1=None, transpose=False):
     if not m.any():
         return u
     I = hanging_interpolation(mesh.p)
-    last = mesh.n - 1
-    for d in range(3):                                 # direction normal to the constrained face: 0 = x (index i), 1 = y, 2 = z
-        sel_d = (m & HANG_FACE[d]) != 0
-        if not sel_d.any():
-            continue
-        assert not ((m[sel_d] & (7 ^ HANG_FACE[d])) != 0).any(), "one constrained face per cell"
-        t1, t2 = [e for e in range(3) if e != d]
-        for side in (0, 1):
-            for h1 in (0, 1):
-                for h2 in (0, 1):
-                    sel = sel_d & (((m & HANG_SIDE[d]) != 0) == bool(side)) & (((m & HANG_HALF[t1]) != 0) == bool(h1)) \
-                        & (((m & HANG_HALF[t2]) != 0) == bool(h2))
-                    if not sel.any():
-                        continue
-                    ids = np.nonzero(sel)[0]
-                    # array axes of [cell][k][j][i]: direction e lives on axis 3 - e
-                    face = np.take(u[ids], side * last, axis=3 - d + 0)          # [cells][ax_hi][ax_lo][...]
-                    hi, lo = max(t1, t2), min(t1, t2)                            # remaining axes in order (higher direction first)
-                    A_hi = I[h2 if hi == t2 else h1]
-                    A_lo = I[h1 if lo == t1 else h2]
-                    if transpose:
-                        face = np.einsum("ab,ce,nac...->nbe...", A_hi, A_lo, face)
-                    else:
-                        face = np.einsum("ab,ce,nbe...->nac...", A_hi, A_lo, face)
-                    idx = [ids, slice(None), slice(None), slice(None)]
-                    idx[1 + (2 - d)] = side * last
-                    u[tuple(idx)] = face
+    n = mesh.n
+    extra = (None,) * (u.ndim - 4)
+    for mval in np.unique(m[m != 0]):
+        ids = np.nonzero(m == mval)[0]
+        blk = u[ids]
+        for d, on in enumerate(hanging_lines(int(mval), n)):
+            if on is None:
+                continue
+            M = I[1 if (mval & HANG_HALF[d]) else 0]
+            axis = 1 + (2 - d)
+            new = np.moveaxis(np.tensordot(M.T if transpose else M, blk, axes=([1], [axis])), 0, axis)
+            blk = np.where(on[(None,) + (slice(None),) * 3 + extra], new, blk)
+        u[ids] = blk
     return u
 
 
@@ -307,6 +321,127 @@ class HangingBrickMesh:
             for e in range(3):
                 bnd |= (c0[:, e] < eps) | (c0[:, e] > self.L[e] - eps)
         self.constrained = np.nonzero(bnd)[0].astype(np.uint32)
+
+    def cell_node_coords(self):
+        """positions of every cell's OWN nodes through the hanging-node interpolation of the coordinate field"""
+        n = self.n
+        X = self.coords[self.l2g.astype(np.int64)].reshape(self.n_cells, n, n, n, 3).copy()
+        return resolve_hanging(self, X)
+
+
+class RefinedBrickMesh:
+    """General two-level 2:1 mesh: a brick of Nx x Ny x Nz cubes of side H, the cubes flagged in `refine` ([z][y][x] bool) split
+    into 8.  Fine cells on the rim of the refined region carry constrained faces (up to three: corners of the region) and,
+    at re-entrant corners, constrained edges (HANG_EDGE).  Global DoFs: every node of an unrefined cube and every fine node
+    that does not lie on a coarser cell; constrained faces / edges name the coarse neighbour's DoFs.  Zero Dirichlet on
+    the whole boundary.  Cells: unrefined cubes first (x fastest), then the children (parent x fastest, child x fastest)."""
+
+    def __init__(self, p, coarse, refine, H=1.0, deform_amp=0.0):
+        self.p, self.n = p, p + 1
+        n, last = self.n, p
+        nodes, _ = gll_01(n)
+        Nx, Ny, Nz = coarse
+        refine = np.asarray(refine, bool).reshape(Nz, Ny, Nx)
+        self.L = (Nx * H, Ny * H, Nz * H)
+        keys, coords = {}, []
+
+        def node_ids(origin, size):
+            X = np.stack(np.meshgrid(origin[2] + size * nodes, origin[1] + size * nodes, origin[0] + size * nodes, indexing="ij")[::-1], -1)
+            ids = np.empty((n, n, n), np.int64)
+            for idx in np.ndindex(n, n, n):
+                k = tuple(np.round(X[idx] / H * 2 ** 30).astype(np.int64))
+                if k not in keys:
+                    keys[k] = len(coords)
+                    coords.append(X[idx])
+                ids[idx] = keys[k]
+            return ids, X
+
+        inside = lambda c: 0 <= c[0] < Nx and 0 <= c[1] < Ny and 0 <= c[2] < Nz
+        is_coarse = lambda c: inside(c) and not refine[c[2], c[1], c[0]]
+        is_fine = lambda c: inside(c) and refine[c[2], c[1], c[0]]
+        ax = np.arange(n)
+        coord = [ax[None, None, :], ax[None, :, None], ax[:, None, None]]
+        cells, masks, coarse_l2g = [], [], {}
+        for cz in range(Nz):
+            for cy in range(Ny):
+                for cx in range(Nx):
+                    if not refine[cz, cy, cx]:
+                        ids, _ = node_ids((cx * H, cy * H, cz * H), H)
+                        coarse_l2g[(cx, cy, cz)] = ids
+                        cells.append(ids.ravel())
+                        masks.append(0)
+        self.n_coarse_cells = len(cells)
+        unit = np.eye(3, dtype=int)
+        fine_nodes = []                                        # (cell index, coordinates, replaced) for the conformity audit below
+        for cz in range(Nz):
+            for cy in range(Ny):
+                for cx in range(Nx):
+                    if not refine[cz, cy, cx]:
+                        continue
+                    P = np.array([cx, cy, cz])
+                    for ch in np.ndindex(2, 2, 2):
+                        c = ch[::-1]                            # child position (x, y, z)
+                        sgn = [1 if c[e] else -1 for e in range(3)]
+                        msk = 0
+                        replaced = np.zeros((n, n, n), bool)
+                        src = np.full((n, n, n), -1, np.int64)
+                        for e in range(3):
+                            Q = tuple(P + sgn[e] * unit[e])
+                            if is_coarse(Q):
+                                msk |= HANG_FACE[e]
+                                sel = np.broadcast_to(coord[e] == c[e] * last, (n, n, n))
+                                opp = np.broadcast_to(coord[e] == (1 - c[e]) * last, (n, n, n))
+                                src[sel] = coarse_l2g[Q][opp]
+                                replaced |= sel
+                        for d in range(3):
+                            e1, e2 = [e for e in range(3) if e != d]
+                            Q1, Q2 = tuple(P + sgn[e1] * unit[e1]), tuple(P + sgn[e2] * unit[e2])
+                            Qd = tuple(P + sgn[e1] * unit[e1] + sgn[e2] * unit[e2])
+                            if is_coarse(Qd) and is_fine(Q1) and is_fine(Q2):
+                                msk |= HANG_EDGE[d]
+                                sel = np.broadcast_to((coord[e1] == c[e1] * last) & (coord[e2] == c[e2] * last), (n, n, n))
+                                opp = np.broadcast_to((coord[e1] == (1 - c[e1]) * last) & (coord[e2] == (1 - c[e2]) * last), (n, n, n))
+                                src[sel] = coarse_l2g[Qd][opp]
+                                replaced |= sel
+                        if msk:
+                            for e in range(3):
+                                if c[e]:
+                                    msk |= HANG_SIDE[e] | HANG_HALF[e]
+                        origin = ((cx + c[0] / 2) * H, (cy + c[1] / 2) * H, (cz + c[2] / 2) * H)
+                        X = np.stack(np.meshgrid(origin[2] + H / 2 * nodes, origin[1] + H / 2 * nodes, origin[0] + H / 2 * nodes, indexing="ij")[::-1], -1)
+                        ids = src.copy()
+                        for idx in np.ndindex(n, n, n):
+                            if not replaced[idx]:
+                                k = tuple(np.round(X[idx] / H * 2 ** 30).astype(np.int64))
+                                if k not in keys:
+                                    keys[k] = len(coords)
+                                    coords.append(X[idx])
+                                ids[idx] = keys[k]
+                        fine_nodes.append((X, replaced))
+                        cells.append(ids.ravel())
+                        masks.append(msk)
+        # audit: a fine node that keeps its own DoF must not lie on an unrefined cube unless it IS one of that cube's nodes
+        cube_nodes = {c: set(map(int, ids.ravel())) for c, ids in coarse_l2g.items()}
+        for (X, replaced), ids in zip(fine_nodes, cells[self.n_coarse_cells:]):
+            ids = ids.reshape(n, n, n)
+            for idx in np.ndindex(n, n, n):
+                if replaced[idx]:
+                    continue
+                x = X[idx] / H
+                for c, own in cube_nodes.items():
+                    if all(c[e] - 1e-12 <= x[e] <= c[e] + 1 + 1e-12 for e in range(3)):
+                        assert int(ids[idx]) in own, "hanging node without a constraint"
+        self.l2g = np.asarray(cells, dtype=np.uint32)
+        self.constraint_mask = np.asarray(masks, dtype=np.uint32)
+        self.n_cells = self.l2g.shape[0]
+        self.n_dofs = len(coords)
+        c0 = np.asarray(coords)
+        eps = 1e-12
+        bnd = np.zeros(self.n_dofs, bool)
+        for e in range(3):
+            bnd |= (c0[:, e] < eps) | (c0[:, e] > self.L[e] - eps)
+        self.constrained = np.nonzero(bnd)[0].astype(np.uint32)
+        self.coords = deform_sine(c0, self.L, deform_amp) if deform_amp != 0.0 else c0
 
     def cell_node_coords(self):
         """positions of every cell's OWN nodes through the hanging-node interpolation of the coordinate field"""

@@ -293,3 +293,102 @@ def test_hanging_node_path_of_the_oracle(p, amp):
     m2 = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=amp)
     m2.constrained = np.zeros(0, np.uint32)                     # unconstrained RHS: sum_i int phi_i = volume
     assert abs(O.assemble_rhs(m2).sum() - vol) < 1e-12 * vol
+
+
+def _refine_pattern(name):
+    if name == "L":                # re-entrant edge along z: constrained EDGES on the cells diagonal to the unrefined column
+        coarse, r = (2, 2, 2), np.zeros((2, 2, 2), bool)
+        r[:, 0, 0] = r[:, 0, 1] = r[:, 1, 0] = True
+    elif name == "core":           # one refined cube inside 3^3: cells with one, two and three constrained faces
+        coarse, r = (3, 3, 3), np.zeros((3, 3, 3), bool)
+        r[1, 1, 1] = True
+    elif name == "diagonal":       # two refined cubes touching along an edge, one more touching at a vertex only
+        coarse, r = (2, 2, 2), np.zeros((2, 2, 2), bool)
+        r[0, 0, 0] = r[0, 1, 1] = r[1, 0, 1] = True
+    else:                          # staircase: every kind of rim in one mesh
+        coarse, r = (3, 2, 2), np.zeros((2, 2, 3), bool)
+        r[0, 0, 0] = r[0, 0, 1] = r[0, 1, 0] = r[1, 0, 0] = r[1, 1, 2] = True
+    return coarse, r
+
+
+@pytest.mark.parametrize("pattern", ["L", "core", "diagonal", "stairs"])
+@pytest.mark.parametrize("p,amp", [(1, 0.0), (2, 0.0), (3, 0.0), (4, 0.0), (2, 0.03)])
+def test_hanging_nodes_on_general_two_level_meshes(pattern, p, amp):
+    """Known answers for constrained faces in any number per cell plus constrained edges (RefinedBrickMesh, hanging_lines):
+    * the mesh generator's own audit: no fine node on a coarser cell is left without a constraint;
+    * a polynomial of degree <= p per variable, sampled at the global DoFs, is reproduced at EVERY cell's own nodes by the
+      gather + fix-up (undeformed mesh): the finite-element space is conforming across faces, edges and corners of the rim;
+    * its energy u^T A u equals the exact integral (Gauss(p+1) integrates degree 2p per variable exactly);
+    * constants in the null space, symmetry (scatter = adjoint of the gather), quadrature weights sum to the volume,
+      unconstrained right-hand side sums to the volume."""
+    if pattern in ("core", "stairs") and p == 4:
+        pytest.skip("size")
+    coarse, r = _refine_pattern(pattern)
+    m = O.RefinedBrickMesh(p, coarse, r, H=0.5, deform_amp=amp)
+    n = m.n
+    kinds = set(int(x) for x in m.constraint_mask)
+    faces = {bin(k & 7).count("1") for k in kinds}
+    if pattern == "core":
+        assert faces == {0, 3}                                   # the 8 children all sit in a corner of the refined cube
+    if pattern == "L":
+        assert any(k & sum(O.HANG_EDGE) for k in kinds)          # the re-entrant corner
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    Lx, Ly, Lz = m.L
+    vol_exact = Lx * Ly * Lz
+    _, JxW, _ = O.jacobians(m, N, D, w)
+    vol = JxW.sum()
+    coef = O.merged_metric(m, N, D, w)
+    if amp == 0.0:
+        assert abs(vol - vol_exact) < 1e-13
+        f = lambda X: X[..., 0] ** p + 2.0 * X[..., 1] * X[..., 2] - 0.5 * X[..., 2] ** p * X[..., 0]
+        u = f(m.coords)
+        ul = O.resolve_hanging(m, u[m.l2g.astype(np.int64)].reshape(m.n_cells, n, n, n).copy())
+        Xc = m.cell_node_coords()
+        nodes, _ = O.gll_01(n)
+        for c in range(m.n_coarse_cells, m.n_cells):             # fine cells: cubes of side H/2 on their own GLL nodes
+            lo = Xc[c].reshape(-1, 3).min(0)
+            for e, ax in ((0, 2), (1, 1), (2, 0)):
+                line = np.moveaxis(Xc[c][..., e], ax, 0).reshape(n, -1)
+                assert np.abs(line - (lo[e] + 0.25 * nodes)[:, None]).max() < 1e-14
+        assert np.abs(ul - f(Xc)).max() < 1e-13
+        # exact energy by a tensor Gauss rule on the whole brick (the integrand is a polynomial)
+        xg, wg = O.gauss_01(2 * p + 2)
+        G = np.stack(np.meshgrid(Lx * xg, Ly * xg, Lz * xg, indexing="ij"), -1)
+        W = np.einsum("i,j,k->ijk", wg, wg, wg) * vol_exact
+        x, y, z = G[..., 0], G[..., 1], G[..., 2]
+        gx = p * x ** (p - 1) - 0.5 * z ** p
+        gy = 2.0 * z
+        gz = 2.0 * y - 0.5 * p * z ** (p - 1) * x
+        exact = float(np.sum(W * (gx * gx + gy * gy + gz * gz)))
+        assert abs(u @ O.apply_cells(m, coef, N, D, u) - exact) < 1e-12 * exact
+    assert np.abs(O.apply_cells(m, coef, N, D, np.ones(m.n_dofs))).max() < 1e-12
+    rng = np.random.default_rng(5)
+    u, v = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    vAu = v @ O.apply_cells(m, coef, N, D, u)
+    assert abs(vAu - u @ O.apply_cells(m, coef, N, D, v)) < 1e-11 * abs(vAu)
+    a = np.array([0.3, -1.1, 0.7])
+    ulin = m.coords @ a
+    assert abs(ulin @ O.apply_cells(m, coef, N, D, ulin) - (a @ a) * vol) < 1e-12 * (a @ a) * vol
+    m.constrained = np.zeros(0, np.uint32)
+    assert abs(O.assemble_rhs(m).sum() - vol) < 1e-12 * vol
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_general_hanging_mesh_reproduces_the_planar_one(p):
+    """One planar interface built by both generators (HangingBrickMesh: round-2 known answers; RefinedBrickMesh with the upper
+    x-half refined): the same discrete operator -- A u agrees DoF by DoF (matched through the coordinates)."""
+    H = 0.5
+    a = O.HangingBrickMesh(p, 1, 2, 1, 2, H=H)
+    r = np.zeros((1, 2, 2), bool)
+    r[:, :, 1] = True
+    b = O.RefinedBrickMesh(p, (2, 2, 1), r, H=H)
+    assert a.n_dofs == b.n_dofs and a.n_cells == b.n_cells
+    key = lambda X: [tuple(np.round(x * 2 ** 30).astype(np.int64)) for x in X]
+    pos = {k: i for i, k in enumerate(key(a.coords))}
+    perm = np.asarray([pos[k] for k in key(b.coords)])          # DoF i of b is DoF perm[i] of a
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    ca, cb = O.merged_metric(a, N, D, w, O.kappa_step64), O.merged_metric(b, N, D, w, O.kappa_step64)
+    u = np.random.default_rng(8).standard_normal(a.n_dofs)
+    ya = O.apply_cells(a, ca, N, D, u)
+    yb = O.apply_cells(b, cb, N, D, u[perm])
+    assert np.linalg.norm(yb - ya[perm]) < 1e-12 * np.linalg.norm(ya)
