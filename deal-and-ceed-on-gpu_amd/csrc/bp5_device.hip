@@ -93,9 +93,16 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     std::vector<uint32_t> hm(d->constraint_mask_host, d->constraint_mask_host + d->n_cells);
     for (uint32_t m : hm) {
       if (!m) continue;
-      const uint32_t faces = m & 7u;
-      if (m >> 9) return fail(BP5_ERR_UNSUPPORTED, "constraint_mask: unknown bits (isolated hanging edges are not supported)");
-      if (faces != 1u && faces != 2u && faces != 4u) return fail(BP5_ERR_UNSUPPORTED, "constraint_mask: exactly one constrained face per flagged cell");
+      if (m >> 12) return fail(BP5_ERR_INVALID, "constraint_mask: unknown bits");
+      if (!(m & 0xe07u)) return fail(BP5_ERR_INVALID, "constraint_mask: position bits without a constrained face or edge");
+      for (int e = 0; e < 3; ++e) // one position per direction: it locates faces / edges AND selects the half of the coarse entity
+        if (((m >> (3 + e)) & 1u) != ((m >> (6 + e)) & 1u)) {
+          // planar round-2 masks name only what they use (SIDE of the face's normal, HALF of its two tangential directions)
+          const int e1 = e == 0 ? 1 : 0, e2 = e == 2 ? 1 : 2;
+          const bool side_used = ((m >> e) & 1u) || ((m >> (9 + e1)) & 1u) || ((m >> (9 + e2)) & 1u);
+          const bool half_used = ((m >> e1) & 1u) || ((m >> e2) & 1u) || ((m >> (9 + e)) & 1u);
+          if (side_used && half_used) return fail(BP5_ERR_INVALID, "constraint_mask: BP5_HANG_SIDE_d and BP5_HANG_HALF_d disagree");
+        }
       mf->has_hanging = true;
     }
     if (mf->has_hanging) {

@@ -79,20 +79,24 @@ struct ApplyArgs {
 };
 
 // constraint-mask decoding shared by every kernel that gathers or scatters through local_to_global (bp5.h: BP5_HANG_*):
-// bits 0-2 constrained face normal to x / y / z (one per cell), bits 3-5 that face sits at xi = 1, bits 6-8 the fine cell covers
-// the upper half of the coarse cell along x / y / z (used for the two directions tangential to the face)
-struct HangFace {
-  int d, side, t1, t2, h1, h2;
-  __device__ __forceinline__ explicit HangFace(uint32_t m)
-  {
-    d = (m & 1u) ? 0 : (m & 2u) ? 1 : 2;
-    side = (m >> (3 + d)) & 1u;
-    t1 = d == 0 ? 1 : 0;
-    t2 = d == 2 ? 1 : 2;
-    h1 = (m >> (6 + t1)) & 1u;
-    h2 = (m >> (6 + t2)) & 1u;
-  }
-};
+// bits 0-2 the face normal to x / y / z is constrained (any subset), bits 3-5 the cell's position in its parent along x / y / z
+// (locates the constrained faces / edges: xi = 0 or 1), bits 6-8 the same position as "upper half" selector of the interpolation
+// ALONG x / y / z, bits 9-11 the edge along x / y / z at the corner named by bits 3-5 is constrained on its own.
+// The fix-up is one 1-D interpolation per direction d on the cell-local lines along d that lie on a constrained face tangential
+// to d or on the constrained edge along d.
+__device__ __forceinline__ bool hang_dir_any(uint32_t m, int d)
+{
+  const int e1 = d == 0 ? 1 : 0, e2 = d == 2 ? 1 : 2;
+  return ((m >> e1) | (m >> e2) | (m >> (9 + d))) & 1u;
+}
+__device__ __forceinline__ bool hang_on_line(uint32_t m, int d, int i, int j, int k, int last)
+{
+  const int idx[3] = {i, j, k};
+  const int e1 = d == 0 ? 1 : 0, e2 = d == 2 ? 1 : 2;
+  const bool s1 = idx[e1] == (int)((m >> (3 + e1)) & 1u) * last, s2 = idx[e2] == (int)((m >> (3 + e2)) & 1u) * last;
+  return (((m >> e1) & 1u) && s1) || (((m >> e2) & 1u) && s2) || (((m >> (9 + d)) & 1u) && s1 && s2);
+}
+#define BP5_HANG_ANY 0xe07u // FACE and EDGE bits
 
 // In-register n x n mat-vec with wave-uniform matrix entries.  The 1-D tables are symmetric
 // under x -> 1-x:  N[q][i] = N[n-1-q][n-1-i],  D[q][i] = -D[n-1-q][n-1-i]  (enforced bitwise by
@@ -165,28 +169,26 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v)
 template <int n, int TW, bool TR, typename L>
 __device__ __forceinline__ void pencil_hang_resolve(uint32_t m, const double *__restrict__ I, double (&u)[n], double *T, int a_, int b_, bool active)
 {
-  const HangFace f(m & 0x1ffu);
-  const bool on = active && (m & 7u) != 0;
+  const bool on = active && (m & BP5_HANG_ANY) != 0;
 #define TH(k, j, i) T[(k) * L::PS + (j) * L::RS + (i)]
-  for (int sweep = 0; sweep < 2; ++sweep) {
-    const int t = sweep == 0 ? f.t1 : f.t2;
-    const double *M = I + (sweep == 0 ? f.h1 : f.h2) * n * n;
+  for (int d = 0; d < 3; ++d) { // every lane of the team takes every sweep (cells of one team differ in their masks)
+    const double *M = I + ((m >> (6 + d)) & 1u) * n * n;
     team_sync<TW>();
     if (active) {
 #pragma unroll
       for (int k = 0; k < n; ++k) TH(k, b_, a_) = u[k];
     }
     team_sync<TW>();
-    if (on) {
+    if (on && hang_dir_any(m, d)) {
 #pragma unroll
       for (int k = 0; k < n; ++k) {
+        if (!hang_on_line(m, d, a_, b_, k, n - 1)) continue;
         const int idx[3] = {a_, b_, k};
-        if (idx[f.d] != f.side * (n - 1)) continue;
         double acc = 0.0;
         for (int q = 0; q < n; ++q) {
           int e[3] = {a_, b_, k};
-          e[t] = q;
-          const double w = TR ? M[q * n + idx[t]] : M[idx[t] * n + q];
+          e[d] = q;
+          const double w = TR ? M[q * n + idx[d]] : M[idx[d] * n + q];
           acc += w * TH(e[2], e[1], e[0]);
         }
         u[k] = acc;
@@ -1984,20 +1986,18 @@ struct Cell3 {
 template <int n, bool TR>
 __device__ void hang_resolve3(uint32_t m, const double *I, double *v, double *t, int i, int j, int k)
 {
-  if (!(m & 7u)) return; // block-uniform
-  const HangFace f(m & 0x1ffu);
+  if (!(m & BP5_HANG_ANY)) return; // block-uniform
   const int idx[3] = {i, j, k}, q = i + n * (j + n * k);
-  const bool on = idx[f.d] == f.side * (n - 1);
-  for (int sweep = 0; sweep < 2; ++sweep) {
-    const int td = sweep == 0 ? f.t1 : f.t2;
-    const double *M = I + (sweep == 0 ? f.h1 : f.h2) * n * n;
+  for (int d = 0; d < 3; ++d) {
+    if (!hang_dir_any(m, d)) continue; // block-uniform
+    const double *M = I + ((m >> (6 + d)) & 1u) * n * n;
     double acc = v[q];
-    if (on) {
+    if (hang_on_line(m, d, i, j, k, n - 1)) {
       acc = 0.0;
       for (int r = 0; r < n; ++r) {
         int e[3] = {i, j, k};
-        e[td] = r;
-        acc += (TR ? M[r * n + idx[td]] : M[idx[td] * n + r]) * v[e[0] + n * (e[1] + n * e[2])];
+        e[d] = r;
+        acc += (TR ? M[r * n + idx[d]] : M[idx[d] * n + r]) * v[e[0] + n * (e[1] + n * e[2])];
       }
     }
     t[q] = acc;
@@ -2155,7 +2155,7 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
     __syncthreads();
     const double *N = tab_gauss;
     double y = Cell3<n>::template tensor3<true>(N, N, N, v, t1, t2, i, j, k);
-    if (hm & 7u) { // adjoint of the hanging-node interpolation before the scatter
+    if (hm & BP5_HANG_ANY) { // adjoint of the hanging-node interpolation before the scatter
       v[q] = y;
       __syncthreads();
       hang_resolve3<n, true>(hm, hang_I, v, t1, i, j, k);

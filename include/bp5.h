@@ -37,7 +37,7 @@ enum {
   BP5_ERR_HIP = 2,            /* a HIP runtime call failed (AssertCuda, bp5/solver.h:396-397)  */
   BP5_ERR_NO_DEVICE = 3,      /* no gfx950 device visible: there is NO CPU fallback            */
   BP5_ERR_RCCL = 4,           /* an RCCL call failed                                           */
-  BP5_ERR_UNSUPPORTED = 5,    /* e.g. isolated hanging edges, two constrained faces on one cell */
+  BP5_ERR_UNSUPPORTED = 5,    /* e.g. the operator diagonal on a mesh with hanging nodes */
   BP5_ERR_BREAKDOWN = 6,      /* CG breakdown: p.Ap == 0 or NaN (ExcDivideByZero, solver.h:501)*/
   BP5_ERR_NO_CONVERGENCE = 7  /* SolverControl::NoConvergence, bp5/solver.h:539-540            */
 };
@@ -151,19 +151,25 @@ typedef struct {
   const uint32_t *constraint_mask_host;   /* [n_cells]                                          */
 } bp5_mf_desc;
 
-/* constraint_mask bits.  A fine cell one of whose faces lies on a coarser neighbour ("hanging" face; planar 2:1 interfaces:
- * at most one such face per cell, isolated hanging edges are refused with BP5_ERR_UNSUPPORTED):
- *   BP5_HANG_FACE_d   the face normal to direction d is constrained;
- *   BP5_HANG_SIDE_d   ... and it is the face at xi_d = 1 (else xi_d = 0);
- *   BP5_HANG_HALF_t   for the two directions t tangential to that face: the fine face covers the upper half [1/2, 1] of the
- *                     coarse face along t (else the lower half).
- * local_to_global of the (p+1)^2 entries ON that face names the COARSE face's DoFs in the same orientation.  Gathers
- * (read_dof_values, and the node coordinates of the geometry) interpolate them to the fine face's nodes with the two 1-D
- * matrices I_h[a][b] = phi_b(xi_a / 2 + h / 2); scatters (distribute_local_to_global, RHS assembly) apply the adjoint.
- * (deal.II's own bit layout is not part of the reference repository; this one is the library's.) */
+/* constraint_mask bits of a fine cell that touches coarser cells ("hanging" faces / edges of 2:1 refined meshes):
+ *   BP5_HANG_FACE_d   the face normal to direction d lies on a coarser neighbour (any subset: cells on the rim of a refined
+ *                     region have one, at its edges two, at its corners three);
+ *   BP5_HANG_EDGE_d   the edge along d lies on a coarser cell's edge although neither face through it is constrained
+ *                     (re-entrant corners of the refined region);
+ *   BP5_HANG_SIDE_e   position of the cell in its parent along e (0 / 1): constrained faces normal to e sit at xi_e = that side,
+ *                     a constrained edge along d at the corner (SIDE_e1, SIDE_e2) of the two other directions;
+ *   BP5_HANG_HALF_d   the same position, as selector of the interpolation ALONG d: the cell covers the upper half [1/2, 1] of
+ *                     the coarse face / edge (else the lower half).  (A cell with one constrained face may name only the SIDE
+ *                     of the normal and the HALF of the two tangential directions; where both are used they must agree.)
+ * local_to_global of the (p+1)^2 entries ON a constrained face names the COARSE face's DoFs in the same orientation, the p+1
+ * entries on a constrained edge the coarse edge's.  Gathers (read_dof_values, and the node coordinates of the geometry) apply,
+ * per direction d, the 1-D matrix I_h[a][b] = phi_b(xi_a / 2 + h / 2), h = HALF_d, to every cell-local line along d that lies on
+ * a constrained face tangential to d or on the constrained edge along d; scatters (distribute_local_to_global, RHS
+ * assembly) apply the adjoint.  (deal.II's own bit layout is not part of the reference repository; this one is the library's.) */
 enum { BP5_HANG_FACE_X = 1, BP5_HANG_FACE_Y = 2, BP5_HANG_FACE_Z = 4,
        BP5_HANG_SIDE_X = 8, BP5_HANG_SIDE_Y = 16, BP5_HANG_SIDE_Z = 32,
-       BP5_HANG_HALF_X = 64, BP5_HANG_HALF_Y = 128, BP5_HANG_HALF_Z = 256 };
+       BP5_HANG_HALF_X = 64, BP5_HANG_HALF_Y = 128, BP5_HANG_HALF_Z = 256,
+       BP5_HANG_EDGE_X = 512, BP5_HANG_EDGE_Y = 1024, BP5_HANG_EDGE_Z = 2048 };
 
 /* == MatrixFree::reinit(mapping, dof_handler, constraints, quad, additional_data),
  *    bp5/step-64.cu:234-248.  Uploads the flat arrays; computes nothing yet. */

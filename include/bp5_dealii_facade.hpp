@@ -74,15 +74,18 @@ template <int dim, int fe_degree, bool transpose, typename Number>
 __device__ inline void resolve_hanging_nodes(const unsigned int constraint_mask, Number *values)
 {
   static_assert(dim == 3, "dim == 3");
-  if (!(constraint_mask & 7u)) return; // block-uniform
+  constexpr unsigned int any = BP5_HANG_FACE_X | BP5_HANG_FACE_Y | BP5_HANG_FACE_Z | BP5_HANG_EDGE_X | BP5_HANG_EDGE_Y | BP5_HANG_EDGE_Z;
+  if (!(constraint_mask & any)) return; // block-uniform
   constexpr int n = fe_degree + 1;
-  const int d = (constraint_mask & BP5_HANG_FACE_X) ? 0 : (constraint_mask & BP5_HANG_FACE_Y) ? 1 : 2;
-  const int side = (constraint_mask >> (3 + d)) & 1u;
   const int idx[3] = {(int)(threadIdx.x % n), (int)threadIdx.y, (int)threadIdx.z};
   const int q = idx[0] + n * (idx[1] + n * idx[2]);
-  const bool on = idx[d] == side * (n - 1);
-  for (int t = 0; t < 3; ++t) { // the two directions tangential to the face, one sweep each
-    if (t == d) continue;
+  bool at_side[3]; // this entry lies on the side of the cell that the mask's position bits name
+  for (int e = 0; e < 3; ++e) at_side[e] = idx[e] == (int)((constraint_mask >> (3 + e)) & 1u) * (n - 1);
+  for (int t = 0; t < 3; ++t) { // one sweep per direction: the lines along t on constrained faces tangential to t, and the constrained edge along t
+    const int e1 = t == 0 ? 1 : 0, e2 = t == 2 ? 1 : 2;
+    const bool face1 = (constraint_mask >> e1) & 1u, face2 = (constraint_mask >> e2) & 1u, edge = (constraint_mask >> (9 + t)) & 1u;
+    if (!(face1 || face2 || edge)) continue; // block-uniform
+    const bool on = (face1 && at_side[e1]) || (face2 && at_side[e2]) || (edge && at_side[e1] && at_side[e2]);
     const double *M = global_hanging_interpolation + ((constraint_mask >> (6 + t)) & 1u) * n * n;
     Number acc = values[q];
     if (on) {

@@ -229,7 +229,8 @@ def test_round2_entry_points_validate_their_arguments_without_a_gpu():
     assert L.bp5_mf_set_overlap(null, 1) == 1 and L.bp5_mf_set_cg_fusion(null, 1) == 1
     assert b"null" in L.bp5_last_error().lower() or b"bad" in L.bp5_last_error().lower()
     # the hanging-node mask bits are part of the ABI (include/bp5.h BP5_HANG_*): the oracle uses the same values
-    assert (O.HANG_FACE, O.HANG_SIDE, O.HANG_HALF) == ((1, 2, 4), (8, 16, 32), (64, 128, 256))
+    assert (O.HANG_FACE, O.HANG_SIDE, O.HANG_HALF, O.HANG_EDGE) == ((1, 2, 4), (8, 16, 32), (64, 128, 256), (512, 1024, 2048))
     text = open(os.path.join(bp5_pkg.ROOT, "include", "bp5.h")).read()
-    for name, val in (("BP5_HANG_FACE_X", 1), ("BP5_HANG_FACE_Z", 4), ("BP5_HANG_SIDE_X", 8), ("BP5_HANG_HALF_X", 64), ("BP5_HANG_HALF_Z", 256)):
+    for name, val in (("BP5_HANG_FACE_X", 1), ("BP5_HANG_FACE_Z", 4), ("BP5_HANG_SIDE_X", 8), ("BP5_HANG_HALF_X", 64), ("BP5_HANG_HALF_Z", 256),
+                      ("BP5_HANG_EDGE_X", 512), ("BP5_HANG_EDGE_Z", 2048)):
         assert f"{name} = {val}" in text

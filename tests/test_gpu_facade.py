@@ -92,13 +92,19 @@ def test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, 
         assert m.n_dofs == 343 and abs(norm_ref - soft) < 1e-7               # agrees to the six digits remembered
 
 
-@pytest.mark.parametrize("p", [2, 3])
-def test_facade_resolves_hanging_nodes(tmp_path, p):
+@pytest.mark.parametrize("p,general", [(2, False), (3, False), (2, True), (3, True)])
+def test_facade_resolves_hanging_nodes(tmp_path, p, general):
     """FEEvaluation::read_dof_values / distribute_local_to_global of the facade honour Data::constraint_mask
     (resolve_hanging_nodes, bp5/fe_evaluation_gl.h:150-151,167-168): a user functor written like the reference's
     LocalPoissonOperator, on a mesh with one 2:1 refined interface handed over as flat arrays, against the library's
     hanging-node kernel and the oracle."""
-    m = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=0.03)
+    if general:      # staircase-shaped refined region: cells with one, two and three constrained faces, and constrained edges
+        r = np.zeros((2, 2, 3), bool)
+        r[0, 0, 0] = r[0, 0, 1] = r[0, 1, 0] = r[1, 0, 0] = r[1, 1, 2] = True
+        m = O.RefinedBrickMesh(p, (3, 2, 2), r, H=0.5, deform_amp=0.03)
+        assert any(int(k) & (512 | 1024 | 2048) for k in m.constraint_mask)
+    else:
+        m = O.HangingBrickMesh(p, 2, 2, 1, 3, H=0.5, deform_amp=0.03)
     prefix = str(tmp_path / "hang")
     s = O.deterministic_src(m.n_dofs, seed=81)
     m.l2g.astype(np.uint32).tofile(prefix + "_l2g.bin")

@@ -1295,15 +1295,73 @@ def test_hanging_nodes_on_a_2_to_1_refined_mesh(p, quad, amp):
         op.mf_data.set_apply_variant(3)                   # no other kernel honours the masks
     with pytest.raises(pkg.BP5Error):
         op.compute_diagonal()
-    # masks the library does not implement are refused at create time
+    # malformed masks are refused at create time
     bad = _hanging_namespace(m)
-    bad.constraint_mask = m.constraint_mask.copy()
-    bad.constraint_mask[-1] = 1 | 2                       # two constrained faces
-    with pytest.raises(pkg.BP5Error):
-        pkg.PoissonOperator(bad, quad)
-    bad.constraint_mask[-1] = 1 << 9                      # unknown bit (isolated hanging edge)
-    with pytest.raises(pkg.BP5Error):
-        pkg.PoissonOperator(bad, quad)
+    for wrong in (1 << 12,                                # unknown bit
+                  8 | 64,                                 # position bits without a constrained face or edge
+                  1 | 2 | 8 | 16 | 128):                  # faces x and y: SIDE_X (where face x sits) and HALF_X (face y's interpolation along x) disagree
+        bad.constraint_mask = m.constraint_mask.copy()
+        bad.constraint_mask[-1] = wrong
+        with pytest.raises(pkg.BP5Error):
+            pkg.PoissonOperator(bad, quad)
+
+
+def _refined(pattern, p, amp):
+    if pattern == "L":                # re-entrant edge along z: constrained EDGES
+        coarse, r = (2, 2, 2), np.zeros((2, 2, 2), bool)
+        r[:, 0, 0] = r[:, 0, 1] = r[:, 1, 0] = True
+    elif pattern == "core":           # one refined cube inside 3^3: three constrained faces on every child
+        coarse, r = (3, 3, 3), np.zeros((3, 3, 3), bool)
+        r[1, 1, 1] = True
+    else:                             # staircase: one, two, three faces and edges in one mesh
+        coarse, r = (3, 2, 2), np.zeros((2, 2, 3), bool)
+        r[0, 0, 0] = r[0, 0, 1] = r[0, 1, 0] = r[1, 0, 0] = r[1, 1, 2] = True
+    return O.RefinedBrickMesh(p, coarse, r, H=0.5, deform_amp=amp)
+
+
+@pytest.mark.parametrize("pattern,p,quad,amp", [("L", 1, 0, 0.0), ("L", 2, 0, 0.03), ("L", 3, 1, 0.0), ("L", 4, 0, 0.02), ("core", 2, 0, 0.0),
+                                                ("core", 3, 0, 0.03), ("stairs", 1, 1, 0.0), ("stairs", 2, 0, 0.03), ("stairs", 3, 0, 0.0),
+                                                ("stairs", 5, 0, 0.0), ("L", 6, 0, 0.0), ("L", 8, 0, 0.02)])
+def test_hanging_nodes_on_general_two_level_meshes(pattern, p, quad, amp):
+    """General 2:1 meshes (oracle: RefinedBrickMesh, pinned by its known-answer tests): cells on the rim of a refined region with
+    one, two (its edges) and three (its corners) constrained faces, and constrained edges at re-entrant corners (BP5_HANG_EDGE_*).
+    Geometry (the node coordinates are interpolated like any FE function), operator, RHS, both solvers, L2 norm."""
+    torch = _t()
+    m = _refined(pattern, p, amp)
+    kinds = set(int(k) for k in m.constraint_mask)
+    if pattern == "L":
+        assert any(k & (512 | 1024 | 2048) for k in kinds)
+    if pattern == "stairs":
+        assert {bin(k & 7).count("1") for k in kinds} >= {0, 1, 2, 3} and any(k & (512 | 1024 | 2048) for k in kinds)
+    _, _, w, N, D = O.shape_tables(p, quad)
+    coef_ref = O.merged_metric(m, N, D, w, O.kappa_step64)
+    op = pkg.PoissonOperator(_hanging_namespace(m), quad, pkg.COEF_STEP64)
+    assert op.mf_data.get_apply_variant() == 90
+    got = op.mf_data.coef_reference_layout(op.coef).cpu().numpy().reshape(6, m.n_cells, -1)
+    assert np.abs(got - coef_ref).max() < 1e-12 * np.abs(coef_ref).max()
+    c = m.constrained.astype(np.int64)
+
+    def A(s):
+        d = O.apply_cells(m, coef_ref, N, D, s)
+        d[c] = s[c]
+        return d
+
+    s = O.deterministic_src(m.n_dofs, seed=72)
+    dst = op.initialize_dof_vector()
+    dst.fill_(float("nan"))
+    op.vmult(dst, dev(s))
+    assert rel(dst.cpu().numpy(), A(s)) < TOL_OP
+    b = op.assemble_rhs()
+    b_ref = O.assemble_rhs(m)
+    assert rel(b.cpu().numpy(), b_ref) < TOL_OP
+    its = 3 if p == 1 else 6
+    xr, _, _ = O.cg_plain(A, b_ref, its)
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(its, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == its and rel(x.cpu().numpy(), xr) < TOL_CG
+    assert abs(op.l2_norm_solution(x) - O.l2_norm_solution(m, xr)) < 1e-11 * O.l2_norm_solution(m, xr)
 
 
 # ------------------------------------------------------------------ edge cases
