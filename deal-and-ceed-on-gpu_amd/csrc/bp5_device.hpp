@@ -499,6 +499,9 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
 #ifdef BP5_TIMING_BUILDS
     // timing-only ablations of variant 3 (results are wrong by construction): 20 + ABL mask
 #define ABL_CASE(M) BP5_CASE(4, 20 + (M)) return launch_apply_t<4, false, 4, 25, 1, true, M>(mf, coef, src, dst, c0, c1)
+#define ABL_CASE_HI(P, L, M) BP5_CASE(P, 20 + (M)) return launch_apply_t<P, false, 4, L, 1, true, M>(mf, coef, src, dst, c0, c1)
+    ABL_CASE_HI(8, 81, 1); ABL_CASE_HI(8, 81, 2); ABL_CASE_HI(8, 81, 4); ABL_CASE_HI(8, 81, 8); ABL_CASE_HI(8, 81, 9); ABL_CASE_HI(8, 81, 11);
+    ABL_CASE_HI(6, 49, 1); ABL_CASE_HI(6, 49, 2); ABL_CASE_HI(6, 49, 8); ABL_CASE_HI(6, 49, 9);
     BP5_CASE(4, 7) return coll ? launch_apply_t<4, true, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 256>(mf, coef, src, dst, c0, c1);
     BP5_CASE(4, 8) return coll ? launch_apply_t<4, true, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 4, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
     BP5_CASE(4, 9) return coll ? launch_apply_t<4, true, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1) : launch_apply_t<4, false, 2, 25, 1, true, 512>(mf, coef, src, dst, c0, c1);
