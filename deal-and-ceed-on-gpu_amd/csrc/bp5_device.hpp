@@ -575,6 +575,16 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
     }
     // 56 on the other degrees with a wave-local cell shape (p = 2, 3, 5, 6, 7): sequential tiles, run-length write-out, packed
     // indices; p >= 5 keep two workgroups per CU (registers), fused CG dot products when the solver asks for them
+#ifdef BP5_TIMING_BUILDS
+    if constexpr (DEG == 6 || DEG == 8 || DEG == 5) if (variant == 99 || variant == 91 || variant == 93) { // cycle stamps / no write-out / no metric loads
+      constexpr int LPCB = block_lpc(DEG);
+      if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "needs aligned cell blocks");
+      struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+      if (variant == 99) return launch_block_t<DEG, false, LPCB, 4096 + 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, true);
+      if (variant == 91) return launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1>(mf, coef, src, dst, true);
+      return launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 2>(mf, coef, src, dst, true);
+    }
+#endif
     if constexpr (DEG != 4 && block_lpc(DEG) != 0) if (variant == 56) {
       constexpr int LPCB = block_lpc(DEG);
       if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
