@@ -156,9 +156,10 @@ def main():
     # small problems (config 2's 54^3; the 116x116x14.5 slab of one of 8 ranks): 4x4x2 bricks give the persistent workgroups twice
     # as many bricks to balance (profiles/r2: 0.427 vs 0.439 ms per iteration at 54^3)
     small = base[0] * base[1] * base[2] // (world if strong else 1) < 400000
-    # p = 1, 3, 7: bricks sized for the deterministic block kernel (profiles/r2 configs: +9 % at p = 1, +29 % at p = 3, on par at p = 7);
-    # p = 5, 6, 8: the atomic pencil kernel is still 5-9 % ahead of it and gains 3-6 % from 8x8x8 parity-class bricks; p = 2: lexicographic
-    default_block = {1: (8, 8, 8), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (8, 8, 8), 6: (8, 8, 8), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
+    # p = 1, 3, 6, 7: bricks sized for the deterministic block kernel (profiles/r2 configs: +9 % at p = 1, +29 % at p = 3, +5 % at p = 7, on
+    # par at p = 6 with the even-odd contractions); p = 5, 8: the atomic pencil kernel is still ahead of it and gains 3-6 % from 8x8x8
+    # parity-class bricks; p = 2: lexicographic
+    default_block = {1: (8, 8, 8), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (8, 8, 8), 6: (4, 4, 2), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
     block = tuple(args.cell_block) if args.cell_block else default_block
     blocked = all(b > 0 for b in block)
     mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world,
@@ -264,7 +265,7 @@ def main():
         fused = bool(ctl.dot_products_fused)
         B_kernel = B_op + (24.0 if fused else 0.0)
         achieved = B_kernel * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
-        lpc = {1: 4, 2: 16, 3: 16, 4: 32, 5: 64, 6: 64, 7: 64}.get(p, 0)
+        lpc = {1: 4, 2: 16, 3: 16, 4: 32, 5: 64, 6: 64, 7: 64, 8: 128}.get(p, 0)
         coll = "true" if args.quadrature == "gll" else "false"
         kname = f"apply_block_kernel<{p},{coll},{lpc},1,1337344>" if fused else \
             {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: f"apply_block_kernel<{p},{coll},{lpc},1,288768>"}.get(ev, f"apply variant {ev}")

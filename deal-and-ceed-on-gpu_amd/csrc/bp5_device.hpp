@@ -154,6 +154,31 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set);
 bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1);
 
 // ------------------------------------------------------------------------------------ operator launches
+// 1-D tables as the kernels read them: the (anti)symmetric half of N and D (p <= 4), or their even-odd split (mv_even_odd)
+template <int n>
+inline void pack_even_odd(const double *M, bool anti, double *out)
+{
+  constexpr int c = (n + 1) / 2, h = n / 2, m = (n - 1) / 2;
+  for (int q = 0; q < n; ++q)
+    for (int i = 0; i < h; ++i) {
+      const double E = 0.5 * (M[q * n + i] + M[q * n + n - 1 - i]), O = 0.5 * (M[q * n + i] - M[q * n + n - 1 - i]);
+      if (q < c) out[q * h + i] = anti ? O : E;
+      if (q < h) out[c * h + q * h + i] = anti ? E : O;
+    }
+  if (n & 1)
+    for (int q = 0; q < c; ++q) out[c * h + h * h + q] = M[q * n + m];
+}
+template <int n>
+inline void fill_shape(ShapeArg<n> &sh, const bp5_mf *mf)
+{
+  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
+  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  if constexpr (n >= EO_MIN_N) {
+    pack_even_odd<n>(mf->tab.N, false, sh.N);
+    pack_even_odd<n>(mf->tab.D, true, sh.D);
+  }
+}
+
 template <int P, bool COLL, int TW, int LPC, int TPB, bool PF, int ABL = 0>
 inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1)
 {
@@ -171,8 +196,7 @@ inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   const uint32_t nblk = (a.n_teams + TPB - 1) / TPB;
   a.teams_per_xcd = (nblk + 7) / 8;
   ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  fill_shape(sh, mf);
   const size_t lds = (size_t)TPB * CPT * L::CS * sizeof(double);
   hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF, ABL>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
                      sh);
@@ -251,8 +275,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  fill_shape(sh, mf);
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   const dim3 grid(n_wg), block(256);
@@ -323,8 +346,7 @@ inline int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
   a.n_teams = (c1 + CPT - 1) / CPT - c0 / CPT;
   a.teams_per_xcd = (a.n_teams + 7) / 8;
   ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  fill_shape(sh, mf);
   const size_t lds = (size_t)CPT * L::CS * sizeof(double);
   const dim3 grid(a.teams_per_xcd * 8), block(64 * TW);
   const bool whole = (c0 == 0 && c1 == mf->n_cells);
@@ -373,8 +395,7 @@ inline int launch_march_t(bp5_mf *mf, const double *coef, const double *src, dou
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = mp.n_teams; a.teams_per_xcd = mp.teams_per_xcd;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
   ShapeArg<n> sh;
-  memcpy(sh.N, mf->tab.N, sizeof(sh.N));
-  memcpy(sh.D, mf->tab.D, sizeof(sh.D));
+  fill_shape(sh, mf);
   const size_t lds = (size_t)CPT * L::CS * sizeof(double);
   hipLaunchKernelGGL((apply_march_kernel<P, COLL, TW, LPC, PF, ABL>), dim3(mp.teams_per_xcd * 8), dim3(64 * TW), lds, mf->stream, a, mp, sh);
   KERNEL_CHECK();
@@ -674,7 +695,7 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
     BP5_TRY(get_plan(mf, 10, tp, &dp));                                                                            \
     ApplyArgs a; a.l2g = mf->d_l2g; a.coef = coef; a.src = src; a.dst = dst; a.plane_stride = mf->coef_plane_stride; a.cell_stride = mf->coef_cell_stride; \
     a.cell_begin = c0; a.cell_end = c1; a.n_teams = (c1 + 9) / 10 - c0 / 10; a.teams_per_xcd = (a.n_teams + 7) / 8;  \
-    ShapeArg<5> sh; memcpy(sh.N, mf->tab.N, sizeof(sh.N)); memcpy(sh.D, mf->tab.D, sizeof(sh.D));                  \
+    ShapeArg<5> sh; fill_shape(sh, mf);                  \
     hipLaunchKernelGGL((apply_team_kernel<4, false, 4, 25, true, SC_OWNER_SET, M>), dim3(a.teams_per_xcd * 8), dim3(256), \
                        (10 * LdsLayout<5, 25>::CS * sizeof(double)), mf->stream, a, tp, sh);                          \
     KERNEL_CHECK(); return BP5_OK; }

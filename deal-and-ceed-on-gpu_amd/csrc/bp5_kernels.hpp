@@ -103,9 +103,85 @@ __device__ __forceinline__ bool hang_on_line(uint32_t m, int d, int i, int j, in
 // the host, bp5_host.cpp), so only the first half of each table is ever read: 26 instead of 50
 // doubles at p = 4, which keeps the tables in SGPRs without spilling.
 // out[q] (+)= sum_i M[q][i] in[i]   (TR: M[i][q]);  ANTI selects the antisymmetric table D.
+// n >= EO_MIN_N (p >= 6): even-odd form of the same product.  With e_i = in_i + in_{n-1-i}, o_i = in_i - in_{n-1-i} a
+// table that is (anti)symmetric under reversal of both indices needs ceil(n/2) x floor(n/2) + floor(n/2)^2 multiply-adds
+// instead of n^2 (n = 7: 25 + 12 additions against 49; n = 9: 41 + 16 against 81) -- the deterministic block kernel is
+// ALU-bound in evaluate / integrate at these degrees (profiles/r2: p = 6 cycle stamps; measured on one box, on / off: block kernel
+// p = 6 1.358 / 1.471 ms, p = 7 1.154 / 1.236 ms, pencil kernel p = 8 1.085 / 1.190 ms; p = 5 (n = 6) loses: 1.716 / 1.527 ms).  Table layout (host: pack_even_odd in
+// bp5_device.hpp), c = ceil(n/2), h = floor(n/2), m = (n-1)/2:  P[c][h], S[h][h], mid[c] with
+//   E[q][i] = (M[q][i] + M[q][n-1-i]) / 2,  O[q][i] = (M[q][i] - M[q][n-1-i]) / 2,  mid[q] = M[q][m];
+//   symmetric table: P = E, S = O;  antisymmetric table: P = O, S = E.
+#ifndef BP5_EO_MIN_N
+#define BP5_EO_MIN_N 7
+#endif
+constexpr int EO_MIN_N = BP5_EO_MIN_N;
+template <int n, bool TR, bool ANTI, bool ADD>
+__device__ __forceinline__ void mv_even_odd(const double *__restrict__ M, const double (&in)[n], double (&out)[n])
+{
+  constexpr int c = (n + 1) / 2, h = n / 2, m = (n - 1) / 2;
+  constexpr bool odd = (n & 1) != 0;
+  const double *__restrict__ P = M, *__restrict__ S = M + c * h, *__restrict__ mid = M + c * h + h * h;
+  double e[h], o[h];
+#pragma unroll
+  for (int i = 0; i < h; ++i) {
+    e[i] = in[i] + in[n - 1 - i];
+    o[i] = in[i] - in[n - 1 - i];
+  }
+  if constexpr (!TR) {
+#pragma unroll
+    for (int q = 0; q < h; ++q) {
+      double pv = P[q * h] * (ANTI ? o[0] : e[0]), sv = S[q * h] * (ANTI ? e[0] : o[0]);
+#pragma unroll
+      for (int i = 1; i < h; ++i) {
+        pv = fma(P[q * h + i], ANTI ? o[i] : e[i], pv);
+        sv = fma(S[q * h + i], ANTI ? e[i] : o[i], sv);
+      }
+      if constexpr (odd) {
+        if constexpr (ANTI) sv = fma(mid[q], in[m], sv);
+        else pv = fma(mid[q], in[m], pv);
+      }
+      const double r0 = pv + sv, r1 = pv - sv; // symmetric: A = pv, B = sv: A - B; antisymmetric: A = sv, B = pv: B - A
+      out[q] = ADD ? out[q] + r0 : r0;
+      out[n - 1 - q] = ADD ? out[n - 1 - q] + r1 : r1;
+    }
+    if constexpr (odd) {
+      double pv = P[m * h] * (ANTI ? o[0] : e[0]);
+#pragma unroll
+      for (int i = 1; i < h; ++i) pv = fma(P[m * h + i], ANTI ? o[i] : e[i], pv);
+      if constexpr (!ANTI) pv = fma(mid[m], in[m], pv);
+      out[m] = ADD ? out[m] + pv : pv;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      double av = P[i] * e[0], bv = S[i] * o[0];
+#pragma unroll
+      for (int q = 1; q < h; ++q) {
+        av = fma(P[q * h + i], e[q], av);
+        bv = fma(S[q * h + i], o[q], bv);
+      }
+      if constexpr (odd) av = fma(P[m * h + i], in[m], av);
+      const double r0 = av + bv, r1 = ANTI ? bv - av : av - bv;
+      out[i] = ADD ? out[i] + r0 : r0;
+      out[n - 1 - i] = ADD ? out[n - 1 - i] + r1 : r1;
+    }
+    if constexpr (odd) {
+      double v = mid[0] * (ANTI ? o[0] : e[0]);
+#pragma unroll
+      for (int q = 1; q < h; ++q) v = fma(mid[q], ANTI ? o[q] : e[q], v);
+      if constexpr (!ANTI) v = fma(mid[m], in[m], v);
+      out[m] = ADD ? out[m] + v : v;
+    }
+  }
+}
+
 template <int n, bool TR, bool ANTI, bool ADD>
 __device__ __forceinline__ void mv_sym(const double *__restrict__ M, const double (&in)[n], double (&out)[n])
 {
+  if constexpr (n >= EO_MIN_N) {
+    mv_even_odd<n, TR, ANTI, ADD>(M, in, out);
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < n; ++q) {
     double acc = ADD ? out[q] : 0.0;
