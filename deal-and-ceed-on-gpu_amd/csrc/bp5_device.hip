@@ -552,13 +552,18 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = cgt.x; cr.cg_state = mf->d_st;
       const uint32_t grid = std::min<uint32_t>(cgt.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u); // 1024 columns stay free for the exchange
-      hipLaunchKernelGGL((combine_runs_kernel<false, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      // pairs of consecutive ordinals pay on long passes; short ones (config 2, the strong-scaling ranks) are latency-bound
+      if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      else hipLaunchKernelGGL((combine_runs_kernel<false, true, false>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
       mf->fuse.n_cols += grid;
       return BP5_OK;
     }
-    if (set) hipLaunchKernelGGL(combine_runs_kernel<false>, cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
-    else hipLaunchKernelGGL(combine_runs_kernel<true>, cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    const bool pairs = dp->n_shared >= (8u << 20);
+    if (set && pairs) hipLaunchKernelGGL((combine_runs_kernel<false, false, true>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    else if (set) hipLaunchKernelGGL((combine_runs_kernel<false, false, false>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    else if (pairs) hipLaunchKernelGGL((combine_runs_kernel<true, false, true>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
+    else hipLaunchKernelGGL((combine_runs_kernel<true, false, false>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     KERNEL_CHECK();
     return BP5_OK;
   }

@@ -2351,8 +2351,11 @@ struct CombineRuns {
   uint32_t dot_col0, n_owned, n_tiles;
   const int *cg_state;
 };
-constexpr int COMBINE_TILE = 512; // shared-DoF ordinals per tile: 256 threads x one PAIR of consecutive ordinals
-template <bool ADD, bool DOTS = false>
+constexpr int COMBINE_TILE = 512; // shared-DoF ordinals per tile: 256 threads x two ordinals
+// PAIR: a thread takes two CONSECUTIVE ordinals (16-byte slab loads when both lie in one run): 1 % of a CG iteration at 1e8 DoFs;
+// else ordinals tid and tid + 256 of the tile, one after the other (fewer instructions on the dependent-load chain: 1-2 % of an
+// iteration at 1e7 DoFs, where the pass is latency-bound).  Same sums, bit for bit; the launcher picks by n_shared.
+template <bool ADD, bool DOTS = false, bool PAIR = true>
 __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const double *partial, double *dst)
 {
   __shared__ uint32_t s_start[COMBINE_TILE + 2], s_dof0[COMBINE_TILE + 1], s_soff[COMBINE_TILE + 2];
@@ -2385,6 +2388,26 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
       if (j < cnt) s_dof0[j] = cr.dof0[r_lo + j];
     }
     __syncthreads();
+    if constexpr (!PAIR) {
+#pragma unroll
+      for (uint32_t half = 0; half < 2; ++half) {
+        const uint32_t i = tile * (uint32_t)COMBINE_TILE + half * 256u + threadIdx.x;
+        if (i >= cr.n_shared) break;
+        uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_start[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
+        double sum = 0.0; // (a DoF no cell touches has no slot: its sum is zero)
+        if (b < e) {
+          sum = partial[cr.slots[b] + j];
+          for (uint32_t q = b + 1; q < e; ++q) sum += partial[cr.slots[q] + j];
+        }
+        finish((s_dof0[lo] & 0x7fffffffu) + j, (s_dof0[lo] & 0x80000000u) != 0, sum);
+      }
+      continue;
+    }
     const uint32_t i = tile * (uint32_t)COMBINE_TILE + 2u * threadIdx.x;
     if (i >= cr.n_shared) continue;
     uint32_t lo = 0, hi = cnt; // invariant: s_start[lo] <= i < s_start[hi]
