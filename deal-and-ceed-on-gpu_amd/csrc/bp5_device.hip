@@ -1202,14 +1202,16 @@ struct ApplyProfile {
 };
 
 // A.vmult(h, d) inside the solvers: dst already zero on entry when zeroed == true
-// fuse_r != nullptr (merged CG on the packed block kernel, one rank's worth of cells, D == 1): the operator's write-out and
+// n_cols != nullptr (CG on the packed block kernel, one rank's worth of cells): the operator's write-out and
 // combine pass also form the v-dependent dot products of update_b (bp5/solver.h:142-311) and apply the Dirichlet copy; the
-// partial sums land in d_partials, *n_cols columns of them
+// partial sums land in d_partials, *n_cols columns of them.  fuse_r: the residual vector of the merged solver (D == 1), or NULL when
+// only p.v is wanted (standard CG: rows 2-6 of the sums are then meaningless and r is never read)
 static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst, bool zero, ApplyProfile &prof, const double *fuse_r = nullptr,
                         uint32_t *n_cols = nullptr)
 {
   const bool dist = mf->comm && !mf->neighbors.empty(); // halo exchange: whenever there are neighbours (tests: a self neighbour)
-  if (dist && fuse_r) {
+  const bool fusing = n_cols != nullptr;
+  if (dist && fusing) {
     // unsplit exchange + fused dot products: gather, ONE fused launch over all cells (p.v is a sum over cells, so it needs no
     // owner bookkeeping; v.v, r.v, r.r run over owned DoFs), then the ghost contributions travel to their owners, whose
     // unpack kernel corrects v.v and r.v for what it adds
@@ -1257,16 +1259,16 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   }
   BP5_TRY(prof.mark(1));
   if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
-  if (fuse_r) { mf->fuse.on = true; mf->fuse.p = src; mf->fuse.r = fuse_r; mf->fuse.n_cols = 0; }
+  if (fusing) { mf->fuse.on = true; mf->fuse.p = src; mf->fuse.r = fuse_r; mf->fuse.n_cols = 0; }
   const int st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, zero);
-  if (fuse_r) { *n_cols = mf->fuse.n_cols; mf->fuse = bp5_mf::Fuse{}; }
+  if (fusing) { *n_cols = mf->fuse.n_cols; mf->fuse = bp5_mf::Fuse{}; }
   const bool marked = prof.on && mf->prof_mark == nullptr;
   mf->prof_mark = nullptr;
   BP5_TRY(st);
   if (!marked) BP5_TRY(prof.mark(2));
   BP5_TRY(prof.mark(3));
   if (prof.on) prof.used += 4;
-  if (fuse_r) return BP5_OK; // Dirichlet DoFs were written by the fused write-out
+  if (fusing) return BP5_OK; // Dirichlet DoFs were written by the fused write-out
   return bp5_copy_constrained(mf, src, dst);
 }
 
@@ -1323,6 +1325,23 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   mf->fuse = bp5_mf::Fuse{}; // (nothing of an earlier, failed solve survives)
   const int check = prm->check_every;
   int status = BP5_OK;
+  // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank (merged solver: and D == 1;
+  // the plain solver takes only d.h = the quadrature-point energy from the kernel, which no preconditioner enters).
+  // Across ranks the fused iteration uses the unsplit exchange: it saves a pass over p, r, v (24 B/DoF) where the 3-phase split would
+  // hide one DoF plane each way, so under the automatic overlap policy (2) fusion wins at every slab size; only an explicit
+  // bp5_mf_set_overlap(1) keeps the split schedule (and with it the separate dot-product kernel).
+  const bool dist_solve = mf->comm && !mf->neighbors.empty();
+  if (!user && mf->cg_fusion && (plain || !diag) && !(dist_solve && mf->overlap == 1) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
+      effective_variant(mf, 0, mf->n_cells) == 56) {
+    bp5_mf::DevPlan *dp = nullptr;
+    BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));
+    fused_dots = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);
+  }
+  struct OverlapGuard { // the fused exchange stays on the compute stream whatever the slab size
+    bp5_mf *m; int saved;
+    ~OverlapGuard() { m->overlap = saved; }
+  } overlap_guard{mf, mf->overlap};
+  if (fused_dots && dist_solve) mf->overlap = 0;
 
   if (plain) {
     // g = -b, d = -D g, x = 0   (x0 = 0 short-circuit, bp5/solver.h:375-381)
@@ -1333,9 +1352,15 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     hipLaunchKernelGGL(cg_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
     for (int it = 1; it <= prm->max_iter; ++it) {
-      BP5_TRY(vmult(d, h, nullptr, nullptr));
-      hipLaunchKernelGGL(dot_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials);
-      hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_DH, mf->d_st);
+      if (fused_dots) { // d.h = sum over the cells of the quadrature-point energy (+ d^2 on Dirichlet rows, where h = d): row 0 of the fused sums
+        uint32_t n_cols = 0;
+        BP5_TRY(vmult(d, h, nullptr, &n_cols)); // (no residual vector: the write-out does not read g)
+        hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_DH, mf->d_st);
+      } else {
+        BP5_TRY(vmult(d, h, nullptr, nullptr));
+        hipLaunchKernelGGL(dot_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials);
+        hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_DH, mf->d_st);
+      }
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_DH, 1));
       hipLaunchKernelGGL(cg_update_kernel, dim3(grid2), dim3(VB), 0, s, x, g, d, h, diag, n, mf->d_sc, mf->d_st, mf->d_partials);
@@ -1369,23 +1394,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
       else { if (mode == 0) BP5_UPD(0, 2); else if (mode == 1) BP5_UPD(1, 2); else BP5_UPD(2, 2); }
 #undef BP5_UPD
     };
-    // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank and D == 1
-    bool &fused = fused_dots;
-    // Across ranks the fused iteration uses the unsplit exchange: it saves a pass over p, r, v (24 B/DoF) where the 3-phase split would
-    // hide one DoF plane each way, so under the automatic overlap policy (2) fusion wins at every slab size; only an explicit
-    // bp5_mf_set_overlap(1) keeps the split schedule (and with it the separate dot-product kernel).
-    const bool dist_solve = mf->comm && !mf->neighbors.empty();
-    if (!user && mf->cg_fusion && !diag && !(dist_solve && mf->overlap == 1) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
-        effective_variant(mf, 0, mf->n_cells) == 56) {
-      bp5_mf::DevPlan *dp = nullptr;
-      BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));
-      fused = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);
-    }
-    struct OverlapGuard { // the fused exchange stays on the compute stream whatever the slab size
-      bp5_mf *m; int saved;
-      ~OverlapGuard() { m->overlap = saved; }
-    } overlap_guard{mf, mf->overlap};
-    if (fused && dist_solve) mf->overlap = 0;
+    const bool fused = fused_dots;
     // fused iteration across ranks: the values of the NEW p at the DoFs this rank sends are computed into the send buffer first, so the
     // ghost gather of p runs on the communication stream underneath the update kernel (which touches owned entries only); the operator
     // then just waits for the event

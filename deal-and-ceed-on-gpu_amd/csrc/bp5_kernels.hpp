@@ -1895,6 +1895,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
         // as below, in batches of NW pairs per thread: first the run walk and ALL the batch's loads of r (they are
         // independent: one memory latency per batch instead of one per pair), then the stores and the dot products
         constexpr int NW = 5;
+        const bool has_r = bp.cg_r != nullptr; // NULL: only p.v is wanted (standard CG), r is not read
         int r = 0;
         for (int base = 2 * t; base < m; base += NW * 2 * TEAM) {
           uint32_t g0[NW], g1[NW];
@@ -1913,14 +1914,14 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
               const uint32_t gi = g0[j] & BLOCK_DOF_MASK; // (every DoF of a list is < n_local: the vectors hold owned + ghost entries)
               if (i + 1 < m && !run_ends) {
                 kind[j] = 1;
-                if (g0[j] & 0x80000000u) rv[j] = *reinterpret_cast<const bp5_d2u *>(bp.cg_r + gi);
+                if (has_r && (g0[j] & 0x80000000u)) rv[j] = *reinterpret_cast<const bp5_d2u *>(bp.cg_r + gi);
               } else {
                 kind[j] = 2;
-                if (g0[j] & 0x80000000u) rv[j].x = bp.cg_r[gi];
+                if (has_r && (g0[j] & 0x80000000u)) rv[j].x = bp.cg_r[gi];
                 if (i + 1 < m) {
                   kind[j] = 3;
                   g1[j] = rt[BLOCK_MAX_RUNS + r + 1];
-                  if (g1[j] & 0x80000000u) rv[j].y = bp.cg_r[g1[j] & BLOCK_DOF_MASK];
+                  if (has_r && (g1[j] & 0x80000000u)) rv[j].y = bp.cg_r[g1[j] & BLOCK_DOF_MASK];
                 }
               }
             }
@@ -2372,7 +2373,7 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
       }
       dst[g] = vi;
       if (g < cr.n_owned) {
-        const double ri = cr.cg_r[g];
+        const double ri = cr.cg_r ? cr.cg_r[g] : 0.0; // (NULL: only p.v is wanted)
         ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri;
       }
     } else if (ADD) dst[g] += s;
@@ -2515,7 +2516,7 @@ static __global__ void __launch_bounds__(256) unpack_add_dots_kernel(const uint3
     const double c = buf[i], vo = v[g], vn = vo + c;
     v[g] = vn;
     dvv += vn * vn - vo * vo;
-    drv += r[g] * c;
+    if (r) drv += r[g] * c;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { dvv += __shfl_down(dvv, off, 64); drv += __shfl_down(drv, off, 64); }

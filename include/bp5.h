@@ -353,10 +353,12 @@ typedef int (*bp5_vmult_fn)(void *ctx, double *dst, double *src);
 int bp5_cg_solve_operator(bp5_mf *mf, bp5_vmult_fn vmult, void *ctx, const double *diag, const double *b, double *x,
                           const bp5_cg_params *params, bp5_cg_result *result_host);
 
-/* BP5_CG_MERGED on the packed block kernel (p = 4, cell bricks, one rank's cells, diag == NULL): by default the operator's
+/* BP5_CG_MERGED on the packed block kernel (cell bricks, one rank's cells, diag == NULL): by default the operator's
  * write-out and combine pass also form the v-dependent dot products of update_b (bp5/solver.h:142-311: p.v, v.v, r.v, r.r)
  * and write the Dirichlet rows, so the separate pass over p, r, v and the copy_constrained launch disappear.  Same
- * arithmetic, different summation order (still fixed: bitwise reproducible).  0 switches back to the separate kernels. */
+ * arithmetic, different summation order (still fixed: bitwise reproducible).  BP5_CG_PLAIN on that kernel takes d.h (its one
+ * dot product with the operator's result; any diag) from it the same way: the sum over the cells of the quadrature-point
+ * energy, so the pass over d and h disappears.  0 switches back to the separate kernels. */
 int bp5_mf_set_cg_fusion(bp5_mf *mf, int on);
 
 /* event helpers so a host in another language can time on the handle's stream */

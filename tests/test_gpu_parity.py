@@ -758,7 +758,21 @@ def test_merged_cg_with_dot_products_fused_into_the_block_kernel(cells, block, w
     ctl = pkg.IterationNumberControl(iters, 0.0)
     pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix(dinv))
     xj, _, _ = O.cg_plain(pr.vmult, pr.rhs(), iters, diag=1.0 / O.operator_diagonal(pr.mesh, pr.coef, pr.N, pr.D))
-    assert rel(x.cpu().numpy(), xj[perm]) < TOL_CG
+    assert rel(x.cpu().numpy(), xj[perm]) < TOL_CG and not ctl.dot_products_fused
+    # the standard SolverCG takes d.h (its only dot product with the operator's result) from the kernel as the quadrature-point energy:
+    # with and without a preconditioner (D does not enter d.h), inhomogeneous Dirichlet rows included (h = d there)
+    bi_plain, _, _ = O.cg_plain(pr.vmult, bi_lex, 8)
+    for rhs, precond, ref, its in ((b, None, xr, iters), (b, dinv, xj, iters), (bi, None, bi_plain, 8)):
+        outs = []
+        for fused in (True, False, True):
+            op.mf_data.set_cg_fusion(fused)
+            x = op.initialize_dof_vector()
+            ctl = pkg.IterationNumberControl(its, 0.0)
+            pkg.SolverCG(ctl).solve(op, x, rhs, pkg.DiagonalMatrix(precond) if precond is not None else pkg.DiagonalMatrix())
+            assert ctl.dot_products_fused == fused and ctl.last_step() == its and rel(x.cpu().numpy(), ref[perm]) < TOL_CG
+            outs.append(x)
+        assert torch.equal(outs[0], outs[2])
+        assert float((outs[0] - outs[1]).abs().max()) < 1e-12 * float(outs[1].abs().max())
 
 
 @pytest.mark.parametrize("solver_name", ["SolverCG", "SolverCGFullMerge"])

@@ -12,6 +12,7 @@ ap.add_argument("--cell-block", type=int, nargs=3, default=[4, 4, 4])
 ap.add_argument("--variants", type=int, nargs="+", default=[0])
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--solver", choices=["merged", "plain"], default="merged")
 a = ap.parse_args()
 mesh = pkg.BrickMesh(4, a.cells, h=1.0 / a.cells[0], cell_block=a.cell_block, dof_numbering=1, cell_block_order=1)
 op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
@@ -25,7 +26,7 @@ for rnd in range(a.rounds + 1):
             ctl = pkg.IterationNumberControl(a.iters, 0.0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pkg.SolverCGFullMerge(ctl, profile=True).solve(op, x, b, pkg.DiagonalMatrix())
+            (pkg.SolverCGFullMerge if a.solver == "merged" else pkg.SolverCG)(ctl, profile=True).solve(op, x, b, pkg.DiagonalMatrix())
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.iters * 1e3
             if rnd:
