@@ -63,6 +63,9 @@ def _rel(a, b):
     (2, 4, (8, 8, 12), (4, 4, 4), 1, 0),   # the library's own choice at this size (too few bricks for the persistent grid: pencil kernel)
     (3, 2, (3, 3, 7), (0, 0, 0), 0, 0),    # lexicographic cells, atomic pencil kernel
     (2, 6, (4, 4, 5), (4, 4, 2), 1, 56),   # another degree on the block kernel
+    (4, 4, (4, 4, 9), (4, 4, 2), 1, 56),   # four ranks: two middle ranks, slabs of 3 / 2 / 2 / 2 layers (thinner than a brick)
+    (3, 3, (5, 4, 7), (2, 2, 2), 1, 10),   # team kernel (LDS-staged atomics) behind the exchange
+    (2, 1, (6, 5, 6), (0, 0, 0), 0, 0),    # p = 1
 ])
 def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells, block, numbering, variant):
     iters = 8
