@@ -2249,7 +2249,7 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
 // mode (gcell != NULL), the scalar plane times the cell's constant K K^T.
 template <int n>
 __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, uint64_t cell_stride, const double *gcell,
-                                                          const double *tab, uint32_t n_cells, double *diag)
+                                                          const double *tab, uint32_t n_cells, double *diag, const uint32_t *hang_mask)
 {
   constexpr int n2 = n * n, n3 = n2 * n;
   __shared__ double S[n3], t1[n3], t2[n3], NN[n2], DD[n2], ND[n2];
@@ -2275,7 +2275,58 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
       const double y = Cell3<n>::template tensor3<true>(X, Y, Z, S, t1, t2, i, j, k);
       acc += (c < 3) ? y : 2.0 * y;
     }
-    atomic_add_f64(diag + l2g[cell * n3 + q], acc);
+    // entries on constrained faces / edges stand for coarse DoFs: diagonal_hanging_kernel computes theirs
+    const uint32_t hm = hang_mask ? hang_mask[cell] : 0u;
+    const bool coarse_entry = (hm & BP5_HANG_ANY) && (hang_on_line(hm, 0, i, j, k, n - 1) || hang_on_line(hm, 1, i, j, k, n - 1) || hang_on_line(hm, 2, i, j, k, n - 1));
+    if (!coarse_entry) atomic_add_f64(diag + l2g[cell * n3 + q], acc);
+  }
+}
+
+// Diagonal entries of the coarse DoFs a cell with hanging nodes refers to: (R^T A_e R)[s][s] with R the cell's hanging-node
+// interpolation -- R e_s is not a tensor product in general (a DoF on the edge shared by two constrained faces spreads into
+// both), so each such entry takes one application of the cell operator to R e_s.  Setup-time kernel, flagged cells only.
+template <int n>
+__global__ void __launch_bounds__(n *n *n) diagonal_hanging_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, uint64_t cell_stride,
+                                                                  const double *tab, uint32_t n_cells, double *diag, const uint32_t *hang_mask,
+                                                                  const double *hang_I)
+{
+  constexpr int n2 = n * n, n3 = n2 * n;
+  __shared__ double v[n3], w[n3], t1[n3], t2[n3];
+  const int i = threadIdx.x, j = threadIdx.y, k = threadIdx.z;
+  const int q = i + n * (j + n * k);
+  const double *N = tab, *D = tab + n2;
+  for (uint64_t cell = blockIdx.x; cell < n_cells; cell += gridDim.x) {
+    const uint32_t hm = hang_mask[cell];
+    if (!(hm & BP5_HANG_ANY)) continue; // block-uniform
+    double S[6];
+    const uint64_t at = cell * cell_stride + coef_off<n>(i, j + n * k);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[c] = coef[(uint64_t)c * plane_stride + at];
+    for (int s = 0; s < n3; ++s) {
+      const int si = s % n, sj = (s / n) % n, sk = s / n2;
+      if (!(hang_on_line(hm, 0, si, sj, sk, n - 1) || hang_on_line(hm, 1, si, sj, sk, n - 1) || hang_on_line(hm, 2, si, sj, sk, n - 1))) continue; // block-uniform
+      v[q] = q == s ? 1.0 : 0.0;
+      __syncthreads();
+      hang_resolve3<n, false>(hm, hang_I, v, t1, i, j, k); // v = R e_s
+      const double g0 = Cell3<n>::template tensor3<false>(D, N, N, v, t1, t2, i, j, k);
+      const double g1 = Cell3<n>::template tensor3<false>(N, D, N, v, t1, t2, i, j, k);
+      const double g2 = Cell3<n>::template tensor3<false>(N, N, D, v, t1, t2, i, j, k);
+      const double h0 = S[0] * g0 + S[3] * g1 + S[4] * g2, h1 = S[3] * g0 + S[1] * g1 + S[5] * g2, h2 = S[4] * g0 + S[5] * g1 + S[2] * g2;
+      w[q] = h0;
+      __syncthreads();
+      double y = Cell3<n>::template tensor3<true>(D, N, N, w, t1, t2, i, j, k);
+      w[q] = h1;
+      __syncthreads();
+      y += Cell3<n>::template tensor3<true>(N, D, N, w, t1, t2, i, j, k);
+      w[q] = h2;
+      __syncthreads();
+      y += Cell3<n>::template tensor3<true>(N, N, D, w, t1, t2, i, j, k);
+      v[q] = y;
+      __syncthreads();
+      hang_resolve3<n, true>(hm, hang_I, v, t1, i, j, k); // R^T A_e R e_s
+      if (q == s) atomic_add_f64(diag + l2g[cell * n3 + s], v[s]);
+      __syncthreads();
+    }
   }
 }
 static __global__ void reciprocal_kernel(double *v, size_t n)

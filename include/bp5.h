@@ -37,7 +37,7 @@ enum {
   BP5_ERR_HIP = 2,            /* a HIP runtime call failed (AssertCuda, bp5/solver.h:396-397)  */
   BP5_ERR_NO_DEVICE = 3,      /* no gfx950 device visible: there is NO CPU fallback            */
   BP5_ERR_RCCL = 4,           /* an RCCL call failed                                           */
-  BP5_ERR_UNSUPPORTED = 5,    /* e.g. the operator diagonal on a mesh with hanging nodes */
+  BP5_ERR_UNSUPPORTED = 5,    /* e.g. a cell block that does not fit in LDS for a forced variant */
   BP5_ERR_BREAKDOWN = 6,      /* CG breakdown: p.Ap == 0 or NaN (ExcDivideByZero, solver.h:501)*/
   BP5_ERR_NO_CONVERGENCE = 7  /* SolverControl::NoConvergence, bp5/solver.h:539-540            */
 };

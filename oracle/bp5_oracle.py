@@ -603,6 +603,18 @@ def operator_diagonal(mesh, coef, N, D, chunk=4096):
         y = np.zeros((c1 - c0, n, n, n))
         for c, (X, Y, Z, f) in enumerate(fac):
             y += f * np.einsum("ck,bj,ai,...cba->...kji", Z, Y, X, S[c], optimize=True)
+        mask = getattr(mesh, "constraint_mask", None)
+        if mask is not None and np.asarray(mask[c0:c1]).any():
+            # cells with hanging nodes: the entries on constrained faces / edges stand for COARSE DoFs, whose diagonal entry
+            # is that of R^T A_e R (R = the cell's hanging-node interpolation): dense element matrix for those cells
+            n3 = n ** 3
+            for cl in np.nonzero(np.asarray(mask[c0:c1]))[0]:
+                ids = np.arange(c0 + cl, c0 + cl + 1)
+                R = np.eye(n3).reshape(1, n, n, n, n3).copy()
+                sub = type("M", (), dict(p=mesh.p, n=n, n_cells=1, constraint_mask=np.asarray(mask[ids])))
+                R = resolve_hanging(sub, R).reshape(n3, n3)
+                A = element_matrix(coef[:, c0 + cl].reshape(6, -1), N, D)
+                y[cl] = np.einsum("as,ab,bs->s", R, A, R).reshape(n, n, n)
         np.add.at(diag, mesh.l2g[c0:c1].astype(np.int64).ravel(), y.reshape(-1))
     diag[mesh.constrained.astype(np.int64)] = 1.0
     return diag

@@ -1307,8 +1307,8 @@ def test_hanging_nodes_on_a_2_to_1_refined_mesh(p, quad, amp):
     assert np.array_equal(masks, m.constraint_mask)       # MatrixFree::Data::constraint_mask mirrors the input
     with pytest.raises(pkg.BP5Error):
         op.mf_data.set_apply_variant(3)                   # no other kernel honours the masks
-    with pytest.raises(pkg.BP5Error):
-        op.compute_diagonal()
+    d_ref = O.operator_diagonal(m, coef_ref, N, D)        # coarse DoFs on the interface: diagonal of R^T A_e R
+    assert rel(op.compute_diagonal().cpu().numpy(), d_ref) < 1e-13
     # malformed masks are refused at create time
     bad = _hanging_namespace(m)
     for wrong in (1 << 12,                                # unknown bit
@@ -1376,6 +1376,14 @@ def test_hanging_nodes_on_general_two_level_meshes(pattern, p, quad, amp):
         solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
         assert ctl.last_step() == its and rel(x.cpu().numpy(), xr) < TOL_CG
     assert abs(op.l2_norm_solution(x) - O.l2_norm_solution(m, xr)) < 1e-11 * O.l2_norm_solution(m, xr)
+    # Jacobi preconditioner on the refined mesh: the diagonal entries of coarse DoFs named on constrained faces / edges come from
+    # R^T A_e R (R e_s spreads into two faces for a DoF on their common edge: one cell-operator application per such entry)
+    d_ref = O.operator_diagonal(m, coef_ref, N, D)
+    assert rel(op.compute_diagonal().cpu().numpy(), d_ref) < 1e-13
+    xj, _, _ = O.cg_merged(A, b_ref, its, diag=1.0 / d_ref)
+    x = op.initialize_dof_vector()
+    pkg.SolverCGFullMerge(pkg.IterationNumberControl(its, 0.0)).solve(op, x, b, pkg.DiagonalMatrix(op.compute_diagonal(invert=True)))
+    assert rel(x.cpu().numpy(), xj) < TOL_CG
 
 
 # ------------------------------------------------------------------ edge cases

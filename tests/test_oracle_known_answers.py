@@ -392,3 +392,21 @@ def test_general_hanging_mesh_reproduces_the_planar_one(p):
     ya = O.apply_cells(a, ca, N, D, u)
     yb = O.apply_cells(b, cb, N, D, u[perm])
     assert np.linalg.norm(yb - ya[perm]) < 1e-12 * np.linalg.norm(ya)
+
+
+@pytest.mark.parametrize("p,amp", [(1, 0.0), (2, 0.03), (3, 0.0)])
+def test_operator_diagonal_with_hanging_nodes_is_the_diagonal_of_the_assembled_operator(p, amp):
+    """operator_diagonal on a refined mesh (dense R^T A_e R for the cells with constrained faces / edges) against the definition:
+    entry g of A e_g through the matrix-free operator, every DoF of a staircase-refined mesh."""
+    coarse, r = _refine_pattern("stairs")
+    m = O.RefinedBrickMesh(p, coarse, r, H=0.5, deform_amp=amp)
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    coef = O.merged_metric(m, N, D, w, O.kappa_step64)
+    d = O.operator_diagonal(m, coef, N, D)
+    ref = np.zeros(m.n_dofs)
+    for g in range(m.n_dofs):
+        e = np.zeros(m.n_dofs)
+        e[g] = 1.0
+        ref[g] = O.apply_cells(m, coef, N, D, e)[g]
+    ref[m.constrained.astype(np.int64)] = 1.0
+    assert np.abs(d - ref).max() < 1e-13 * np.abs(ref).max()
