@@ -47,6 +47,44 @@ def measured_traffic(key, kernel):
     return best
 
 
+def live_traffic(kernel, workload_args, timeout_s=150):
+    """HBM bytes per launch of `kernel`, measured NOW: two child passes of this very script under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: one counter per pass, `--kernel-trace` only, the program directly after `--`), 3 CG iterations each, counters averaged over
+    the kernel's launches; FETCH_SIZE x 2 on gfx950, both in KiB (MI355X_MICROARCH.md, HBM section).  None if the profiler is not there or a
+    pass fails: the caller then falls back to the committed passes of profiles/*/traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    want = kernel.replace(" ", "")
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bp5_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", "python3",
+                   os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained-iters", "0",
+                   "--no-traffic-pass"] + workload_args
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if want in row["Kernel_Name"].replace(" ", "") and row.get("Counter_Name", counter) == counter]
+            if not vals:
+                return None
+            kib[counter] = sum(vals) / len(vals)
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"traffic_bytes": int(round((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0)), "fetch_size_kib": kib["FETCH_SIZE"],
+            "write_size_kib": kib["WRITE_SIZE"],
+            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench invocation (3 iterations each; FETCH x2 on gfx950, KiB)"}
+
+
 def cpu_baseline(mesh, p, quad, km, budget_s, max_iters):
     """CPU restatement (oracle/bp5_oracle.c, OpenMP) timed on the host cores ON THE BENCH'S OWN MESH (same cells, same
     DoF numbering, same coefficient): a reported baseline ("port"), not deal.II and not the optimisation target.
@@ -106,6 +144,9 @@ def main():
     ap.add_argument("--sustained-reps", type=int, default=3, help="reference protocol: repetitions, best one reported (bp5/step-64.cu:457-463)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only); the committed passes of "
+                         "profiles/*/traffic.json are quoted instead.  Needed under an outer profiler.")
     ap.add_argument("--rehearsal", action="store_true",
                     help="control-flow rehearsal of an N > 1 run on ONE GPU (tests only): every rank on cuda:0, torch.distributed over gloo, "
                          "needs BP5_LIB = libbp5_loopback.so (RCCL refuses two ranks on one device); the JSON line is marked, its numbers mean nothing")
@@ -269,7 +310,16 @@ def main():
         coll = "true" if args.quadrature == "gll" else "false"
         kname = f"apply_block_kernel<{p},{coll},{lpc},1,1337344>" if fused else \
             {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: f"apply_block_kernel<{p},{coll},{lpc},1,288768>"}.get(ev, f"apply variant {ev}")
-        tr = measured_traffic(key, kname) if (args.deform == 0.0 and world == 1) else None
+        tr = None
+        if world == 1 and not args.no_traffic_pass and not args.rehearsal:
+            wl = ["--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
+                  "--variant", args.variant, "--geometry", args.geometry, "--apply-variant", str(args.apply_variant),
+                  "--cells", str(cells[0]), str(cells[1]), str(cells[2]), "--cell-block", str(block[0]), str(block[1]), str(block[2])]
+            tr = live_traffic(kname, wl)
+        if tr is None and args.deform == 0.0 and world == 1:
+            tr = measured_traffic(key, kname)
+            if tr:
+                tr["source"] += ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (not measured in this run)"
         out = {
             "metric": "BP5 DoFs/sec per CG iter (p=4, ~1e8 DoFs) + % HBM roofline at 1/2/4/8 GPUs",
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": iters, "warmup": args.warmup,
@@ -292,7 +342,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["traffic_bytes"] if tr else None,
-                         "traffic_source": (tr["source"] + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (not measured in this run)") if tr else None,
+                         "traffic_source": tr["source"] if tr else None,
                          "algorithmic_bytes": B_kernel * n_dofs_local,
                          "bytes_per_dof": B_kernel, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
                          "operator_ms": ctl.operator_ms_avg,

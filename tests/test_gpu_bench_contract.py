@@ -42,14 +42,24 @@ def test_bench_json_line_small_workload():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                              # ONE JSON line
     d = _check(lines[0], 7, 2)
-    assert d["roofline"]["traffic"] is None             # not the profiled workload
+    # roofline.traffic is measured by the invocation itself: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of this workload
+    r = d["roofline"]
+    assert isinstance(r["traffic"], int) and r["traffic"] > 0 and "child passes of this bench invocation" in r["traffic_source"]
+
+
+def test_bench_quotes_the_committed_pmc_passes_when_the_live_ones_are_switched_off():
+    r = subprocess.run([sys.executable, BENCH, "--cells", "12", "12", "12", "--steps", "3", "--warmup", "1", "--sustained-iters", "0", "--no-cpu-baseline",
+                        "--no-traffic-pass"], capture_output=True, text=True, timeout=900, cwd=bp5_pkg.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None      # (no committed passes for this small workload)
 
 
 def test_bench_under_the_distributed_launcher_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29731", BENCH, "--gpus", "1", "--steps", "4", "--warmup", "1", "--cells", "8", "8", "8",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=bp5_pkg.ROOT, env=env)
+                        "--no-cpu-baseline", "--no-traffic-pass"], capture_output=True, text=True, timeout=900, cwd=bp5_pkg.ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -2,7 +2,7 @@
 # BASELINE configs 2, 4, 5 with bench.py's defaults (and the deterministic block kernel where it is not the default): one JSON line each
 out=${1:-gpurun_out/r2_configs.jsonl}
 : > $out
-B="python bench.py --no-cpu-baseline --sustained-iters 0 --steps 40"
+B="python bench.py --no-cpu-baseline --no-traffic-pass --sustained-iters 0 --steps 40"
 echo "# config 2: p=4, 54^3" >> $out;            $B --cells 54 54 54 2>/dev/null >> $out
 for p in 1 2 3 5 6 7 8; do echo "# config 4: p=$p (default brick order of bench.py)" >> $out; $B --degree $p 2>/dev/null >> $out; done
 echo "# config 4, deterministic block kernel: p=2 8x8x4 bricks" >> $out; $B --degree 2 --cell-block 8 8 4 2>/dev/null >> $out

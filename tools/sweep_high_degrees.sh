@@ -2,7 +2,7 @@
 # p = 5..8 at the config-4 sizes and config 5: bench.py default (atomic pencil kernel where it is ahead) against the deterministic block kernel
 out=${1:-gpurun_out/high_degrees.jsonl}
 : > $out
-B="python bench.py --no-cpu-baseline --sustained-iters 0 --steps 40"
+B="python bench.py --no-cpu-baseline --no-traffic-pass --sustained-iters 0 --steps 40"
 for p in 5 6 7 8; do echo "# p=$p default" >> $out; $B --degree $p 2>/dev/null >> $out; done
 echo "# p=5 block 4x4x2" >> $out; $B --degree 5 --cell-block 4 4 2 2>/dev/null >> $out
 echo "# p=6 block 4x4x2" >> $out; $B --degree 6 --cell-block 4 4 2 2>/dev/null >> $out
