@@ -47,7 +47,7 @@ def measured_traffic(key, kernel):
     return best
 
 
-def live_traffic(kernel, workload_args, timeout_s=150):
+def live_traffic(kernel, workload_args, timeout_s=90):
     """HBM bytes per launch of `kernel`, measured NOW: two child passes of this very script under `rocprofv3 --pmc` (FETCH_SIZE, then
     WRITE_SIZE: one counter per pass, `--kernel-trace` only, the program directly after `--`), 3 CG iterations each, counters averaged over
     the kernel's launches; FETCH_SIZE x 2 on gfx950, both in KiB (MI355X_MICROARCH.md, HBM section).  None if the profiler is not there or a
@@ -58,6 +58,8 @@ def live_traffic(kernel, workload_args, timeout_s=150):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):
+        return None    # this invocation is being profiled itself: no nested profiler
     want = kernel.replace(" ", "")
     kib = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
