@@ -33,11 +33,11 @@ def _free_port():
     return port
 
 
-def _run_ranks(world, args, out, timeout=420):
+def _run_ranks(world, args, out, timeout=420, worker=WORKER):
     assert os.path.exists(LOOPBACK_LIB), "libbp5_loopback.so missing: run __graft_entry__.build() (make -C .../csrc loopback)"
     env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out] + [str(a) for a in args], env=env,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out] + [str(a) for a in args], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs, failed = [], False
     for r, pr in enumerate(procs):
@@ -129,3 +129,60 @@ def test_bench_with_two_ranks_as_the_driver_launches_it():
     assert out["config"]["dofs_per_gpu"] < 65 ** 3 and "274625 DoFs" in out["config"]["workload"]      # ONE 16^3-cell problem split over the ranks
     assert out["config"]["apply_variant"] == 56 and out["config"]["cg_dot_products_fused"] is True      # unsplit exchange, fused dot products
     assert out["value"] > 0 and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("world,p,amp", [(2, 2, 0.03), (3, 3, 0.0), (2, 4, 0.02)])
+def test_refined_mesh_with_hanging_nodes_across_ranks(tmp_path, world, p, amp):
+    """A 2:1 refined mesh (staircase-shaped refined region: constrained faces in every number, constrained edges) cut into slabs along x
+    (tests/loopback/partition.py): constrained faces whose coarse DoFs are GHOSTS of the rank, ragged interfaces, a rank with a single
+    interior cell.  Hanging-node kernel (apply variant 90) behind the exchange in both schedules, RHS and diagonal with
+    compress(add), the solvers, the ghosted L2 norm -- against the oracle on the undivided mesh."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "loopback"))
+    from partition import partition
+    r = np.zeros((2, 2, 3), bool)
+    r[0, 0, 0] = r[0, 0, 1] = r[0, 1, 0] = r[1, 0, 0] = r[1, 1, 2] = True
+    m = O.RefinedBrickMesh(p, (3, 2, 2), r, H=0.5, deform_amp=amp)
+    x_cell = m.cell_node_coords().reshape(m.n_cells, -1, 3).mean(1)[:, 0]
+    cuts = [0.6, 1.1][:world - 1] if world == 3 else [0.8]
+    cell_rank = sum((x_cell > c).astype(int) for c in cuts)
+    pieces = partition(m, cell_rank, world)
+    assert all(pc["n_ghost"] > 0 for pc in pieces[1:]) and any((pc["constraint_mask"] != 0).any() for pc in pieces[1:])
+    for rk, pc in enumerate(pieces):
+        np.savez(os.path.join(str(tmp_path), f"mesh{rk}.npz"), **pc)
+    iters = 6
+    _run_ranks(world, [p, iters], str(tmp_path), worker=os.path.join(ROOT, "tests", "loopback", "worker_mesh.py"))
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    coef = O.merged_metric(m, N, D, w, O.kappa_step64)
+    c = m.constrained.astype(np.int64)
+
+    def A(s):
+        d = O.apply_cells(m, coef, N, D, s)
+        d[c] = s[c]
+        return d
+
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{rk}.npz")) for rk in range(world)]
+    keys = [k for k in ranks[0].files if k[0] in "bAx" or k == "inv_diag"]
+    full = {k: np.full(m.n_dofs, np.nan) for k in keys}
+    for z in ranks:
+        gid = z["gid"].astype(np.int64)
+        assert int(z["variant"]) == 90 and np.isnan(full["b"][gid]).all()
+        for k in keys:
+            full[k][gid] = z[k]
+    assert not any(np.isnan(v).any() for v in full.values())
+    b_ref = O.assemble_rhs(m)
+    assert _rel(full["b"], b_ref) < 1e-13
+    A_ref = A(O.deterministic_src(m.n_dofs, seed=23))
+    assert _rel(full["A0"], A_ref) < 1e-13 and _rel(full["A1"], A_ref) < 1e-13
+    x_plain, _, res_plain = O.cg_plain(A, b_ref, iters)
+    x_merged, _, _ = O.cg_merged(A, b_ref, iters)
+    assert _rel(full["x_plain"], x_plain) < 1e-11 and _rel(full["x_merged"], x_merged) < 1e-11
+    for z in ranks:
+        assert np.array_equal(z["norms"], ranks[0]["norms"])
+    assert abs(ranks[0]["norms"][0] - res_plain) < 1e-9 * np.linalg.norm(b_ref)
+    d_ref = O.operator_diagonal(m, coef, N, D)
+    assert _rel(full["inv_diag"], 1.0 / d_ref) < 1e-13
+    x_jac, _, _ = O.cg_merged(A, b_ref, iters, diag=1.0 / d_ref)
+    assert _rel(full["x_jacobi"], x_jac) < 1e-11
+    l2 = O.l2_norm_solution(m, full["x_merged"])
+    for z in ranks:
+        assert abs(float(z["l2"]) - l2) < 1e-12 * l2
