@@ -1,17 +1,21 @@
 """Test helper: cut an oracle mesh (any object with l2g / coords / constrained / constraint_mask) into rank-local pieces in the
-library's convention -- owned DoF range then ghost range, a DoF shared between ranks is owned by the lowest rank that touches it, the cells
+library's convention -- owned DoF range then ghost range, every DoF shared between ranks owned by ONE of the ranks that touch it, the cells
 that touch no ghost first (n_interior_cells), per-neighbour send / receive lists in ascending global-DoF order on both sides."""
 import numpy as np
 
 
-def partition(m, cell_rank, n_ranks):
-    n3 = m.l2g.shape[1]
+def partition(m, cell_rank, n_ranks, owner_rule="lowest"):
+    """owner_rule "lowest": a shared DoF belongs to the lowest rank touching it (every neighbour relation is one-way, as in the library's
+    slab generator); "alternate": even global ids to the lowest, odd ones to the highest toucher (neighbours that send AND receive)."""
     l2g = m.l2g.astype(np.int64)
     cell_rank = np.asarray(cell_rank)
-    toucher = np.full(m.n_dofs, n_ranks, np.int64)                # lowest rank touching each DoF = its owner
+    lo = np.full(m.n_dofs, n_ranks, np.int64)
+    hi = np.full(m.n_dofs, -1, np.int64)
     for r in range(n_ranks):
         ids = np.unique(l2g[cell_rank == r])
-        toucher[ids] = np.minimum(toucher[ids], r)
+        lo[ids] = np.minimum(lo[ids], r)
+        hi[ids] = np.maximum(hi[ids], r)
+    toucher = lo if owner_rule == "lowest" else np.where(np.arange(m.n_dofs) % 2 == 0, lo, hi)   # the owner of each DoF
     con = np.zeros(m.n_dofs, bool)
     con[m.constrained.astype(np.int64)] = True
     mask = getattr(m, "constraint_mask", None)
@@ -19,7 +23,7 @@ def partition(m, cell_rank, n_ranks):
     for r in range(n_ranks):
         cells = np.nonzero(cell_rank == r)[0]
         used = np.unique(l2g[cells])
-        owned = np.nonzero(toucher == r)[0]                       # (includes DoFs only other ranks' cells ... no: the owner touches it)
+        owned = np.nonzero(toucher == r)[0]
         ghosts = used[toucher[used] != r]
         ghosts = ghosts[np.lexsort((ghosts, toucher[ghosts]))]    # grouped by owner, ascending global id inside a group
         loc = np.full(m.n_dofs, -1, np.int64)

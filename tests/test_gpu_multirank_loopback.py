@@ -186,3 +186,45 @@ def test_refined_mesh_with_hanging_nodes_across_ranks(tmp_path, world, p, amp):
     l2 = O.l2_norm_solution(m, full["x_merged"])
     for z in ranks:
         assert abs(float(z["l2"]) - l2) < 1e-12 * l2
+
+
+def test_quadrant_partition_with_two_way_and_diagonal_neighbours(tmp_path):
+    """A conforming mesh cut into 2 x 2 quadrants in (x, y), four ranks: every rank has neighbours it both sends to and receives from, and
+    ranks 0 and 3 share only an edge of DoFs -- halo plans the library's own slab generator never produces (it is what a
+    p4est-style host hands over).  Same checks as above; the mask array is all zero (conforming), so the default kernels run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "loopback"))
+    from partition import partition
+    p, cells, world, iters = 3, (4, 4, 3), 4, 6
+    pr = O.Problem(p, cells, O.QUAD_GAUSS, deform_amp=0.03, kappa=O.kappa_step64)
+    m = pr.mesh
+    n = p + 1
+    cen = m.coords[m.l2g.astype(np.int64)].reshape(m.n_cells, -1, 3).mean(1)
+    cell_rank = (cen[:, 0] > 2.0).astype(int) + 2 * (cen[:, 1] > 2.0).astype(int)
+    assert sorted(np.bincount(cell_rank)) == [12, 12, 12, 12]
+    pieces = partition(m, cell_rank, world, owner_rule="alternate")
+    assert [pc["n_neighbors"] for pc in pieces] == [3, 2, 2, 3]      # (the DoFs of the common edge belong to rank 0 or 3: ranks 1 and 2 never talk)
+    assert any(pc["send_offsets"][k + 1] > pc["send_offsets"][k] and pc["recv_offsets"][k + 1] > pc["recv_offsets"][k]
+               for pc in pieces for k in range(pc["n_neighbors"]))                       # a two-way neighbour exists
+    for rk, pc in enumerate(pieces):
+        np.savez(os.path.join(str(tmp_path), f"mesh{rk}.npz"), **pc)
+    _run_ranks(world, [p, iters], str(tmp_path), worker=os.path.join(ROOT, "tests", "loopback", "worker_mesh.py"))
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{rk}.npz")) for rk in range(world)]
+    keys = [k for k in ranks[0].files if k[0] in "bAx" or k == "inv_diag"]
+    full = {k: np.full(m.n_dofs, np.nan) for k in keys}
+    for z in ranks:
+        gid = z["gid"].astype(np.int64)
+        assert np.isnan(full["b"][gid]).all()
+        for k in keys:
+            full[k][gid] = z[k]
+    assert not any(np.isnan(v).any() for v in full.values())
+    b_ref = pr.rhs()
+    assert _rel(full["b"], b_ref) < 1e-13
+    A_ref = pr.vmult(O.deterministic_src(m.n_dofs, seed=23))
+    assert _rel(full["A0"], A_ref) < 1e-13 and _rel(full["A1"], A_ref) < 1e-13
+    x_plain, _, _ = O.cg_plain(pr.vmult, b_ref, iters)
+    x_merged, _, _ = O.cg_merged(pr.vmult, b_ref, iters)
+    assert _rel(full["x_plain"], x_plain) < 1e-11 and _rel(full["x_merged"], x_merged) < 1e-11
+    d_ref = O.operator_diagonal(m, pr.coef, pr.N, pr.D)
+    assert _rel(full["inv_diag"], 1.0 / d_ref) < 1e-13
+    x_jac, _, _ = O.cg_merged(pr.vmult, b_ref, iters, diag=1.0 / d_ref)
+    assert _rel(full["x_jacobi"], x_jac) < 1e-11
