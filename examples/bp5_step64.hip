@@ -342,13 +342,18 @@ static int run_check(uint32_t nx, uint32_t ny, uint32_t nz, double deform, const
 }
 
 template <int fe_degree>
-static int run_bench(uint32_t ncell, int n_iterations, int n_repetitions)
+static int run_bench(uint32_t ncell, int n_iterations, int n_repetitions, const uint32_t *cells3 = nullptr, double h = 0.0)
 { // measurement protocol of PoissonProblem::solve, bp5/step-64.cu:422-561
   constexpr int dim = 3;
   bp5_mesh_desc md{};
   md.degree = fe_degree; md.cells[0] = md.cells[1] = md.cells[2] = ncell; md.h = 1.0 / ncell; md.n_ranks = 1;
-  if (fe_degree == 4) { // the ordering bench.py uses: 4x4x4 bricks, parity-class order inside, brick-major numbering
-    md.cell_block[0] = md.cell_block[1] = md.cell_block[2] = 4; md.dof_numbering = 1; md.cell_block_order = 1;
+  if (cells3) { md.cells[0] = cells3[0]; md.cells[1] = cells3[1]; md.cells[2] = cells3[2]; md.h = h; }
+  // the cell order is the host's choice (MatrixFree::reinit reorders cells as well): the bricks bench.py uses for this degree
+  const bool small = (uint64_t)md.cells[0] * md.cells[1] * md.cells[2] < 400000;
+  const uint32_t bricks[9][3] = {{0, 0, 0}, {8, 8, 8}, {0, 0, 0}, {8, 4, 4}, {4, 4, small ? 2u : 4u}, {8, 8, 8}, {4, 4, 2}, {4, 2, 2}, {8, 8, 8}};
+  if (bricks[fe_degree][0]) {
+    for (int d = 0; d < 3; ++d) md.cell_block[d] = bricks[fe_degree][d];
+    md.dof_numbering = 1; md.cell_block_order = 1;
   }
   bp5_mesh *mesh;
   check(bp5_mesh_create_brick(&md, &mesh));
@@ -394,6 +399,33 @@ static int run_bench(uint32_t ncell, int n_iterations, int n_repetitions)
     bp5_event_destroy(e0); bp5_event_destroy(e1);
   }
   bp5_mesh_destroy(mesh);
+  return 0;
+}
+
+// PoissonProblem<dim, degree>::run(cycle_min, cycle_max, n_iterations, n_repetitions, min_run) of the reference's main program
+// (bp5/step-64.cu:619-700,724-730: degree 5, cycles 7...40, 200 iterations, 10 repetitions): the same mesh family -- a brick of
+// (1|2|3) x (1|2) x (1|2) unit cells by the cycle's remainder mod 6, refined globally cycle / 6 times (:633-663) -- and the same
+// output lines per cycle.  min_run skips meshes with fewer DoFs (as the reference's per-rank lower bound does).
+template <int fe_degree>
+static int run_cycles(int cycle_min, int cycle_max, int n_iterations, int n_repetitions, unsigned long long min_run, unsigned long long max_run)
+{
+  for (int cycle = cycle_min; cycle <= cycle_max; ++cycle) {
+    int n_refine = cycle / 6;
+    const int remainder = cycle % 6;
+    uint32_t sub[3] = {1, 1, 1};
+    if (remainder == 1 && cycle > 1) { sub[0] = 3; sub[1] = 2; sub[2] = 2; n_refine -= 1; }
+    if (remainder == 2) sub[0] = 2;
+    else if (remainder == 3) sub[0] = 3;
+    else if (remainder == 4) sub[0] = sub[1] = 2;
+    else if (remainder == 5) { sub[0] = 3; sub[1] = 2; }
+    const uint32_t cells[3] = {sub[0] << n_refine, sub[1] << n_refine, sub[2] << n_refine};
+    const unsigned long long n_dofs = (unsigned long long)(cells[0] * fe_degree + 1) * (cells[1] * fe_degree + 1) * (cells[2] * fe_degree + 1);
+    if (n_dofs < min_run || n_dofs > max_run) continue;
+    printf("Cycle %d\n", cycle);
+    const int st = run_bench<fe_degree>(0, n_iterations, n_repetitions, cells, 1.0 / (1u << n_refine));
+    if (st) return st;
+    fflush(stdout);
+  }
   return 0;
 }
 
@@ -511,7 +543,16 @@ int main(int argc, char **argv)
         case 5: return run_bench<5>(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
       }
     }
-    fprintf(stderr, "usage: %s check <2|3|4> nx ny nz deform prefix | bench <4|5> n iterations repetitions | helmholtz <2|3|4> n prefix\n", argv[0]);
+    else if (argc >= 7 && !strcmp(argv[1], "run")) { // the reference's main(): run <degree> cycle_min cycle_max iterations repetitions [min_dofs [max_dofs]]
+      const int c0 = atoi(argv[3]), c1 = atoi(argv[4]), it = atoi(argv[5]), rep = atoi(argv[6]);
+      const unsigned long long lo = argc >= 8 ? strtoull(argv[7], nullptr, 10) : 0ull, hi = argc >= 9 ? strtoull(argv[8], nullptr, 10) : ~0ull;
+      switch (atoi(argv[2])) {
+        case 4: return run_cycles<4>(c0, c1, it, rep, lo, hi);
+        case 5: return run_cycles<5>(c0, c1, it, rep, lo, hi);
+      }
+    }
+    fprintf(stderr, "usage: %s check <2|3|4> nx ny nz deform prefix | bench <4|5> n iterations repetitions | helmholtz <2|3|4> n prefix | "
+                    "run <4|5> cycle_min cycle_max iterations repetitions [min_dofs [max_dofs]]\n", argv[0]);
     return 2;
   } catch (const std::exception &e) {
     // same shape as the reference's top-level handler, bp5/step-64.cu:735-759

@@ -55,6 +55,27 @@ def test_reference_shaped_benchmark_lines():
         assert m and int(m.group(1)) == 65 ** 3 and float(m.group(2)) > 0
 
 
+def test_reference_main_program_cycles():
+    """`run` is PoissonProblem::run of the reference's main program (bp5/step-64.cu:619-700,724-730): its mesh family (a brick of
+    (1|2|3) x (1|2) x (1|2) cells by cycle mod 6, refined cycle / 6 times), its lines per cycle.  Degree 5 as there, cycles 7...12:
+    the DoF counts are the reference's (1 936 for cycle 7), both solvers print the same solution norm."""
+    r = subprocess.run([EXE, "run", "5", "7", "12", "30", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    cycles = [int(c) for c in re.findall(r"^Cycle (\d+)$", r.stdout, flags=re.M)]
+    assert cycles == [7, 8, 9, 10, 11, 12]
+    want = {7: (3, 2, 2), 8: (2, 1, 1), 9: (3, 1, 1), 10: (2, 2, 1), 11: (3, 2, 1), 12: (1, 1, 1)}
+    dofs = [int(n) for n in re.findall(r"^pcg-merged (\d+) ", r.stdout, flags=re.M)]
+    for c, n in zip(cycles, dofs):
+        ref = c // 6 - (1 if c % 6 == 1 else 0)
+        sub = [s << ref for s in want[c]]
+        assert n == (5 * sub[0] + 1) * (5 * sub[1] + 1) * (5 * sub[2] + 1)
+    assert dofs[0] == 1936
+    norms = re.findall(r"norm ([0-9.e+-]+)$", r.stdout, flags=re.M)
+    assert len(norms) == 12                                          # one line per solve: two solvers x six cycles
+    for a, b in zip(norms[0::2], norms[1::2]):
+        assert abs(float(a) - float(b)) < 1e-9 * float(a)
+
+
 @pytest.mark.parametrize("p,n", [(3, 2), (2, 3)])
 def test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, p, n):
     """HelmholtzProblem::solve (step-64/step-64.cu:505-530): the reference's solvers take ANY operator with vmult
