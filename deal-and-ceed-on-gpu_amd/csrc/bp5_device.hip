@@ -617,12 +617,14 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
       mf->auto_block = lds * (mf->degree <= 4 ? 3 : 2) <= 160 * 1024 && (mf->degree == 4 || dp->packed);
       // persistent workgroups need enough bricks each to balance: round 1 measured 3.6 bricks per workgroup (54^3 cells)
       // 4 % behind the pencil kernel as a bare operator; with the CG dot products fused into the write-out the block kernel
-      // is ahead there too (profiles/r2: 0.439 vs 0.446 ms per iteration), so the bar is 3 bricks per workgroup now
+      // is ahead there too (profiles/r2: 0.439 vs 0.446 ms per iteration), so the bar dropped to 3 bricks per workgroup --
+      // and, measured down the reference's mesh family at p = 4 (profiles/r2 "small meshes"), the fused iteration wins from
+      // 2 bricks per CU on (1.1e6 DoFs: +15 %; 5.4e5 DoFs: par; below: the pencil kernel)
       if (!mf->n_cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
       }
-      if (dp->n_groups < 9u * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
+      if (dp->n_groups < (mf->degree == 4 ? 2u : 9u) * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
     }
   }
   // sub-ranges: worth it only while the range still feeds the persistent grid (else the pencil kernel)
