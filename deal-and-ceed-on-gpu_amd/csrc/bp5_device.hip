@@ -624,7 +624,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
       }
-      if (dp->n_groups < (mf->degree == 4 ? 2u : 9u) * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0;
+      if (dp->n_groups < 2u * (uint32_t)std::max(mf->n_cus, 1)) mf->auto_block = 0; // (p = 3: +34 %, p = 6: +14 %, p = 7: +8 %, p = 1: +4 % at 2-7 bricks per CU)
     }
   }
   // sub-ranges: worth it only while the range still feeds the persistent grid (else the pencil kernel)

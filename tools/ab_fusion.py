@@ -13,8 +13,9 @@ ap.add_argument("--variants", type=int, nargs="+", default=[0])
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--solver", choices=["merged", "plain"], default="merged")
+ap.add_argument("--degree", type=int, default=4)
 a = ap.parse_args()
-mesh = pkg.BrickMesh(4, a.cells, h=1.0 / a.cells[0], cell_block=a.cell_block, dof_numbering=1, cell_block_order=1)
+mesh = pkg.BrickMesh(a.degree, a.cells, h=1.0 / a.cells[0], cell_block=a.cell_block, dof_numbering=1, cell_block_order=1)
 op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
 b, x = op.assemble_rhs(), op.initialize_dof_vector()
 res = {}
