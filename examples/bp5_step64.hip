@@ -410,14 +410,13 @@ template <int fe_degree>
 static int run_cycles(int cycle_min, int cycle_max, int n_iterations, int n_repetitions, unsigned long long min_run, unsigned long long max_run)
 {
   for (int cycle = cycle_min; cycle <= cycle_max; ++cycle) {
-    int n_refine = cycle / 6;
+    // coarse brick by cycle mod 6; the 12-cell brick of remainder 1 takes one global refinement less (cycle 1 itself is the single cube)
+    static const uint32_t family[6][3] = {{1, 1, 1}, {3, 2, 2}, {2, 1, 1}, {3, 1, 1}, {2, 2, 1}, {3, 2, 1}};
     const int remainder = cycle % 6;
-    uint32_t sub[3] = {1, 1, 1};
-    if (remainder == 1 && cycle > 1) { sub[0] = 3; sub[1] = 2; sub[2] = 2; n_refine -= 1; }
-    if (remainder == 2) sub[0] = 2;
-    else if (remainder == 3) sub[0] = 3;
-    else if (remainder == 4) sub[0] = sub[1] = 2;
-    else if (remainder == 5) { sub[0] = 3; sub[1] = 2; }
+    const bool big_brick = remainder == 1 && cycle > 1;
+    const int n_refine = cycle / 6 - (big_brick ? 1 : 0);
+    const uint32_t sub[3] = {remainder == 1 && !big_brick ? 1u : family[remainder][0], remainder == 1 && !big_brick ? 1u : family[remainder][1],
+                             remainder == 1 && !big_brick ? 1u : family[remainder][2]};
     const uint32_t cells[3] = {sub[0] << n_refine, sub[1] << n_refine, sub[2] << n_refine};
     const unsigned long long n_dofs = (unsigned long long)(cells[0] * fe_degree + 1) * (cells[1] * fe_degree + 1) * (cells[2] * fe_degree + 1);
     if (n_dofs < min_run || n_dofs > max_run) continue;
