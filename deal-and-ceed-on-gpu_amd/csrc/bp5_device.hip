@@ -85,6 +85,12 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   BP5_TRY(upload(&mf->d_constrained, d->constrained_host, d->n_constrained));
   mf->h_constrained.assign(nloc, false);
   for (uint32_t s = 0; s < d->n_constrained; ++s) mf->h_constrained[d->constrained_host[s]] = true;
+  {
+    std::vector<uint32_t> bits((size_t)d->n_owned / 32 + 2, 0u);
+    for (uint32_t s = 0; s < d->n_constrained; ++s)
+      if (d->constrained_host[s] < d->n_owned) bits[d->constrained_host[s] >> 5] |= 1u << (d->constrained_host[s] & 31);
+    BP5_TRY(upload(&mf->d_constrained_bits, bits.data(), bits.size()));
+  }
   std::vector<double> tv;
   pack_tab(tab, tv);  BP5_TRY(upload(&mf->d_tab, tv.data(), tv.size()));
   pack_tab(tabg, tv); BP5_TRY(upload(&mf->d_tab_gauss, tv.data(), tv.size()));
@@ -161,7 +167,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   if (!mf) return BP5_OK;
   hipSetDevice(mf->device);
   hipStreamSynchronize(mf->stream);
-  void *ptrs[] = {mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
+  void *ptrs[] = {mf->d_constrained_bits, mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
                   mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell, mf->d_hang_mask, mf->d_hang_I, mf->d_send_dirichlet};
   for (void *p : ptrs) if (p) hipFree(p);
@@ -1262,7 +1268,7 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   const bool owner_scatter = variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells));
   BP5_TRY(prof.mark(0));
   if (zero && !owner_scatter) {
-    HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    if (!mf->solver_prezeroed) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream)); // (else: the update kernel stored the zeros)
     zero = false;
   }
   BP5_TRY(prof.mark(1));
@@ -1277,6 +1283,7 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   BP5_TRY(prof.mark(3));
   if (prof.on) prof.used += 4;
   if (fusing) return BP5_OK; // Dirichlet DoFs were written by the fused write-out
+  if (mf->solver_copies_dirichlet) return BP5_OK; // ... or will be by the solver's dot-product kernel, which reads src and dst anyway
   return bp5_copy_constrained(mf, src, dst);
 }
 
@@ -1395,7 +1402,19 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     // BP5_UPDATE_UNROLL = 1 | 2 | 4; profiles/r2: 1.03 / 1.00 / 0.99 ms per iteration at 1e8 DoFs; default 4)
     static const int unroll = [] { const char *e = getenv("BP5_UPDATE_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 1 || u == 2) ? u : 4; }();
     const int gridu = stream_grid(n, 2 * unroll);
+    // one rank, separate dot-product kernel: the two small launches around an operator that scatters with atomics fold into their
+    // neighbours -- the update kernel stores the zeros the operator needs in v (it holds v's values in registers for the last time),
+    // the dot-product kernel applies the Dirichlet copy while it reads p and v (bitmap of the Dirichlet DoFs)
+    static const bool fold_enabled = [] { const char *e = getenv("BP5_FOLD_SMALL"); return !(e && e[0] == '0'); }(); // A/B knob for tools
+    const bool fold_small = fold_enabled && !fused_dots && !user && !dist_solve;
+    const bool prezero = fold_small && mf->n_ghost == 0 && !variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells)); // (the update kernel covers owned entries)
+    struct FoldGuard { bp5_mf *m; ~FoldGuard() { m->solver_prezeroed = m->solver_copies_dirichlet = false; } } fold_guard{mf};
     auto launch_update = [&](int mode) {
+      if (prezero && mode != 0) {
+        if (mode == 1) hipLaunchKernelGGL((cgm_update_kernel<1, 4, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+        else hipLaunchKernelGGL((cgm_update_kernel<2, 4, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+        return;
+      }
 #define BP5_UPD(M, U) hipLaunchKernelGGL((cgm_update_kernel<M, U>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st)
       if (unroll == 1) { if (mode == 0) BP5_UPD(0, 1); else if (mode == 1) BP5_UPD(1, 1); else BP5_UPD(2, 1); }
       else if (unroll == 4) { if (mode == 0) BP5_UPD(0, 4); else if (mode == 1) BP5_UPD(1, 4); else BP5_UPD(2, 4); }
@@ -1430,8 +1449,13 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
         BP5_TRY(vmult(d, h, g, &n_cols));
         hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_R0, mf->d_st);
       } else {
-        BP5_TRY(vmult(d, h, nullptr, nullptr));
-        hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials);
+        mf->solver_prezeroed = prezero; // (h: zeroed by cgm_init_kernel before the first, by the update kernel before every later application)
+        mf->solver_copies_dirichlet = fold_small;
+        const int st_v = vmult(d, h, nullptr, nullptr);
+        mf->solver_prezeroed = mf->solver_copies_dirichlet = false;
+        BP5_TRY(st_v);
+        hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials,
+                           fold_small ? (const uint32_t *)mf->d_constrained_bits : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
       }
       KERNEL_CHECK();

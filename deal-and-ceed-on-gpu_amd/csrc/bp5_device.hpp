@@ -62,6 +62,8 @@ struct bp5_mf {
   Tables tab, tab_gauss;
   // device arrays
   uint32_t *d_l2g = nullptr, *d_constrained = nullptr, *d_send_idx = nullptr;
+  uint32_t *d_constrained_bits = nullptr; // bit i: DoF i is a Dirichlet DoF (owned range; the solver's dot-product kernel applies the copy)
+  bool solver_prezeroed = false, solver_copies_dirichlet = false; // one operator application inside the merged solver: dst arrives zeroed / the Dirichlet copy follows in the dots kernel
   double *d_coords = nullptr, *d_tab = nullptr, *d_tab_gauss = nullptr;
   // Data mirror (lazy)
   uint32_t *d_l2g_padded = nullptr, *d_constraint_mask = nullptr;

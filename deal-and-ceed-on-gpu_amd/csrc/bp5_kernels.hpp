@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace bp5 {
 
@@ -2785,9 +2786,12 @@ __device__ __forceinline__ void cgm_update_one(double &p, double &r, const doubl
     p = beta * p - di * rn;
   }
 }
-template <int MODE, int U = 2>
-__global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, const double *v, double *x, const double *diag, size_t n,
-                                                       const double *sc, const int *st)
+// ZV: v is consumed here for the last time before the next operator application overwrites it -- an operator kernel that accumulates
+// with atomics needs it zeroed, and this kernel holds v's values in registers anyway: it stores the zeros itself (one zero-fill
+// launch -- two fill kernels in the runtime -- less per iteration)
+template <int MODE, int U = 2, bool ZV = false>
+__global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, typename std::conditional<ZV, double, const double>::type *v, double *x,
+                                                       const double *diag, size_t n, const double *sc, const int *st)
 {
   const bool done = st[ST_DONE];
   if (done && !st[ST_PENDING]) return;
@@ -2828,9 +2832,11 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, co
           if (MODE != 0) *reinterpret_cast<double2 *>(r + i) = rv[u];
         }
         if (touch_x) *reinterpret_cast<double2 *>(x + i) = xv[u];
+        if constexpr (ZV) { if (MODE != 0 && !done) *reinterpret_cast<double2 *>(v + i) = double2{0.0, 0.0}; }
       } else {
         if (touch_rp) { p[i] = pv[u].x; if (MODE != 0) r[i] = rv[u].x; }
         if (touch_x) x[i] = xv[u].x;
+        if constexpr (ZV) { if (MODE != 0 && !done) v[i] = 0.0; }
       }
     }
   }
@@ -2854,8 +2860,10 @@ __global__ void __launch_bounds__(256) cgm_pack_updated_kernel(const uint32_t *i
 }
 
 // update_b (solver.h:142-311): [p.v, v.v, r.v, r.r, r.Dv, v.Dv, r.Dr]
-static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const double *r, const double *v, const double *diag, size_t n,
-                                                     const int *st, double *partials)
+// cbits != NULL: bit i of the bitmap marks a Dirichlet DoF; the operator left its row unset and this kernel applies
+// copy_constrained_values (v = p there, bp5/step-64.cu:275) on the fly, stores it, and uses it in the sums (one launch less per iteration)
+static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, const double *r, double *v, const double *diag, size_t n,
+                                                     const int *st, double *partials, const uint32_t *cbits)
 {
   if (st[ST_DONE]) return;
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2865,13 +2873,22 @@ static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, co
   };
   const size_t stride = (size_t)gridDim.x * VB * 2;
   for (size_t i = ((size_t)blockIdx.x * VB + threadIdx.x) * 2; i < n; i += stride) {
+    const uint32_t cb = cbits ? (cbits[i >> 5] >> (i & 31)) & 3u : 0u; // (i is even: both bits of the pair sit in one word)
     if (i + 1 < n) {
-      const double2 pv = *reinterpret_cast<const double2 *>(p + i), rv = *reinterpret_cast<const double2 *>(r + i),
-                    vv = *reinterpret_cast<const double2 *>(v + i);
+      const double2 pv = *reinterpret_cast<const double2 *>(p + i), rv = *reinterpret_cast<const double2 *>(r + i);
+      double2 vv = *reinterpret_cast<const double2 *>(v + i);
+      if (cb) {
+        if (cb & 1u) vv.x = pv.x;
+        if (cb & 2u) vv.y = pv.y;
+        *reinterpret_cast<double2 *>(v + i) = vv;
+      }
       one(pv.x, rv.x, vv.x, diag ? diag[i] : 1.0);
       one(pv.y, rv.y, vv.y, diag ? diag[i + 1] : 1.0);
-    } else
-      one(p[i], r[i], v[i], diag ? diag[i] : 1.0);
+    } else {
+      double vi = v[i];
+      if (cb & 1u) { vi = p[i]; v[i] = vi; }
+      one(p[i], r[i], vi, diag ? diag[i] : 1.0);
+    }
   }
   block_reduce_store<7>(acc, partials);
 }
