@@ -1357,6 +1357,20 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     ~OverlapGuard() { m->overlap = saved; }
   } overlap_guard{mf, mf->overlap};
   if (fused_dots && dist_solve) mf->overlap = 0;
+  // one rank, separate dot-product kernel: the two small launches around an operator that scatters with atomics fold into their
+  // neighbours -- the update kernel stores the zeros the operator needs in h / v (it holds the values in registers for the last time),
+  // the dot-product kernel applies the Dirichlet copy while it reads both vectors (bitmap of the Dirichlet DoFs)
+  static const bool fold_enabled = [] { const char *e = getenv("BP5_FOLD_SMALL"); return !(e && e[0] == '0'); }(); // A/B knob for tools
+  const bool fold_small = fold_enabled && !fused_dots && !user && !dist_solve;
+  const bool prezero = fold_small && mf->n_ghost == 0 && !variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells)); // (the update kernels cover owned entries)
+  struct FoldGuard { bp5_mf *m; ~FoldGuard() { m->solver_prezeroed = m->solver_copies_dirichlet = false; } } fold_guard{mf};
+  auto folded_vmult = [&](double *src, double *dst) -> int { // the operator between a zero-storing update and a copying dot-product kernel
+    mf->solver_prezeroed = prezero;
+    mf->solver_copies_dirichlet = fold_small;
+    const int st_v = vmult(src, dst, nullptr, nullptr);
+    mf->solver_prezeroed = mf->solver_copies_dirichlet = false;
+    return st_v;
+  };
 
   if (plain) {
     // g = -b, d = -D g, x = 0   (x0 = 0 short-circuit, bp5/solver.h:375-381)
@@ -1366,19 +1380,21 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
     hipLaunchKernelGGL(cg_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
+    if (prezero) HIP_TRY(hipMemsetAsync(h, 0, mf->n_local() * sizeof(double), s)); // once: every later zero-fill is stored by cg_update_kernel
     for (int it = 1; it <= prm->max_iter; ++it) {
       if (fused_dots) { // d.h = sum over the cells of the quadrature-point energy (+ d^2 on Dirichlet rows, where h = d): row 0 of the fused sums
         uint32_t n_cols = 0;
         BP5_TRY(vmult(d, h, nullptr, &n_cols)); // (no residual vector: the write-out does not read g)
         hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_DH, mf->d_st);
       } else {
-        BP5_TRY(vmult(d, h, nullptr, nullptr));
-        hipLaunchKernelGGL(dot_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials);
+        BP5_TRY(folded_vmult(d, h));
+        if (fold_small) hipLaunchKernelGGL(cg_dh_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials, (const uint32_t *)mf->d_constrained_bits);
+        else hipLaunchKernelGGL(dot_kernel, dim3(grid2), dim3(VB), 0, s, d, h, n, mf->d_partials);
         hipLaunchKernelGGL(finalize_kernel<1>, dim3(1), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_DH, mf->d_st);
       }
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_DH, 1));
-      hipLaunchKernelGGL(cg_update_kernel, dim3(grid2), dim3(VB), 0, s, x, g, d, h, diag, n, mf->d_sc, mf->d_st, mf->d_partials);
+      hipLaunchKernelGGL(cg_update_kernel, dim3(grid2), dim3(VB), 0, s, x, g, d, h, diag, n, mf->d_sc, mf->d_st, mf->d_partials, prezero);
       hipLaunchKernelGGL(finalize_kernel<2>, dim3(2), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_GG, mf->d_st);
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
@@ -1402,13 +1418,6 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     // BP5_UPDATE_UNROLL = 1 | 2 | 4; profiles/r2: 1.03 / 1.00 / 0.99 ms per iteration at 1e8 DoFs; default 4)
     static const int unroll = [] { const char *e = getenv("BP5_UPDATE_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 1 || u == 2) ? u : 4; }();
     const int gridu = stream_grid(n, 2 * unroll);
-    // one rank, separate dot-product kernel: the two small launches around an operator that scatters with atomics fold into their
-    // neighbours -- the update kernel stores the zeros the operator needs in v (it holds v's values in registers for the last time),
-    // the dot-product kernel applies the Dirichlet copy while it reads p and v (bitmap of the Dirichlet DoFs)
-    static const bool fold_enabled = [] { const char *e = getenv("BP5_FOLD_SMALL"); return !(e && e[0] == '0'); }(); // A/B knob for tools
-    const bool fold_small = fold_enabled && !fused_dots && !user && !dist_solve;
-    const bool prezero = fold_small && mf->n_ghost == 0 && !variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells)); // (the update kernel covers owned entries)
-    struct FoldGuard { bp5_mf *m; ~FoldGuard() { m->solver_prezeroed = m->solver_copies_dirichlet = false; } } fold_guard{mf};
     auto launch_update = [&](int mode) {
       if (prezero && mode != 0) {
         if (mode == 1) hipLaunchKernelGGL((cgm_update_kernel<1, 4, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
@@ -1449,11 +1458,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
         BP5_TRY(vmult(d, h, g, &n_cols));
         hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_R0, mf->d_st);
       } else {
-        mf->solver_prezeroed = prezero; // (h: zeroed by cgm_init_kernel before the first, by the update kernel before every later application)
-        mf->solver_copies_dirichlet = fold_small;
-        const int st_v = vmult(d, h, nullptr, nullptr);
-        mf->solver_prezeroed = mf->solver_copies_dirichlet = false;
-        BP5_TRY(st_v);
+        BP5_TRY(folded_vmult(d, h)); // (h: zeroed by cgm_init_kernel before the first, by the update kernel before every later application)
         hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials,
                            fold_small ? (const uint32_t *)mf->d_constrained_bits : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);

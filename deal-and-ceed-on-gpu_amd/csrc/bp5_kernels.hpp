@@ -2664,6 +2664,31 @@ static __global__ void __launch_bounds__(VB) dot_kernel(const double *x, const d
   block_reduce_store<1>(acc, partials);
 }
 
+// d.h of the standard solver with copy_constrained_values applied on the fly (h = d on the Dirichlet DoFs of the bitmap, stored)
+static __global__ void __launch_bounds__(VB) cg_dh_kernel(const double *d, double *h, size_t n, double *partials, const uint32_t *cbits)
+{
+  double acc[1] = {0.0};
+  const size_t stride = (size_t)gridDim.x * VB * 2;
+  for (size_t i = ((size_t)blockIdx.x * VB + threadIdx.x) * 2; i < n; i += stride) {
+    const uint32_t cb = (cbits[i >> 5] >> (i & 31)) & 3u;
+    if (i + 1 < n) {
+      const double2 a = *reinterpret_cast<const double2 *>(d + i);
+      double2 b = *reinterpret_cast<const double2 *>(h + i);
+      if (cb) {
+        if (cb & 1u) b.x = a.x;
+        if (cb & 2u) b.y = a.y;
+        *reinterpret_cast<double2 *>(h + i) = b;
+      }
+      acc[0] += a.x * b.x + a.y * b.y;
+    } else {
+      double b = h[i];
+      if (cb & 1u) { b = d[i]; h[i] = b; }
+      acc[0] += d[i] * b;
+    }
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
 // number of nonzero (or NaN) entries, as a double so that it travels through the same reduction / all-reduce
 static __global__ void __launch_bounds__(VB) count_nonzero_kernel(const double *x, size_t n, double *partials)
 {
@@ -2702,8 +2727,10 @@ static __global__ void cg_init_control_kernel(double *sc, int *st)
   st[ST_DONE] = (sc[SC_RES] <= sc[SC_TOL]) ? 1 : 0;
 }
 // x += alpha d ; g += alpha h ; partial sums g.g, g.Dg   with alpha = gh / dh
-static __global__ void __launch_bounds__(VB) cg_update_kernel(double *x, double *g, const double *d, const double *h, const double *diag,
-                                                      size_t n, const double *sc, const int *st, double *partials)
+// zero_h: h is consumed here for the last time before the next operator application; an operator that scatters with atomics needs
+// it zeroed, so this kernel stores the zeros (see cgm_update_kernel<.., ZV>)
+static __global__ void __launch_bounds__(VB) cg_update_kernel(double *x, double *g, const double *d, double *h, const double *diag,
+                                                      size_t n, const double *sc, const int *st, double *partials, bool zero_h)
 {
   if (st[ST_DONE]) return;
   const double alpha = sc[SC_GH] / sc[SC_DH];
@@ -2717,12 +2744,14 @@ static __global__ void __launch_bounds__(VB) cg_update_kernel(double *x, double 
       gv.x += alpha * hv.x; gv.y += alpha * hv.y;
       *reinterpret_cast<double2 *>(x + i) = xv;
       *reinterpret_cast<double2 *>(g + i) = gv;
+      if (zero_h) *reinterpret_cast<double2 *>(h + i) = double2{0.0, 0.0};
       const double z0 = diag ? diag[i] * gv.x : gv.x, z1 = diag ? diag[i + 1] * gv.y : gv.y;
       acc[0] += gv.x * gv.x + gv.y * gv.y;
       acc[1] += gv.x * z0 + gv.y * z1;
     } else {
       const double xi = x[i] + alpha * d[i], gi = g[i] + alpha * h[i];
       x[i] = xi; g[i] = gi;
+      if (zero_h) h[i] = 0.0;
       acc[0] += gi * gi; acc[1] += gi * (diag ? diag[i] * gi : gi);
     }
   }
