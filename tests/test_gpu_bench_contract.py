@@ -43,8 +43,14 @@ def test_bench_json_line_small_workload():
     assert len(lines) == 1                              # ONE JSON line
     d = _check(lines[0], 7, 2)
     # roofline.traffic is measured by the invocation itself: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of this workload
+    # (not when this test itself runs under a profiler: bench.py then starts no nested one and reports null for an unprofiled workload)
+    import shutil
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
     r = d["roofline"]
-    assert isinstance(r["traffic"], int) and r["traffic"] > 0 and "child passes of this bench invocation" in r["traffic_source"]
+    if shutil.which("rocprofv3") and not profiled:
+        assert isinstance(r["traffic"], int) and r["traffic"] > 0 and "child passes of this bench invocation" in r["traffic_source"]
+    else:
+        assert r["traffic"] is None or r["traffic"] > 0
 
 
 def test_bench_quotes_the_committed_pmc_passes_when_the_live_ones_are_switched_off():
