@@ -46,5 +46,43 @@ def main():
     assert drift < 1e-13, drift
     np.savez_compressed(os.path.join(HERE, "p4_kappa_deformed_cg.npz"), b=b, x=x, residuals=np.array(hist), iterations=k)
 
+HANGING_CASES = [(2, 0.03), (3, 0.0)]      # (p, deform): staircase-refined two-level mesh (constrained faces in every number, constrained edges)
+
+
+def hanging_mesh(p, amp):
+    r = np.zeros((2, 2, 3), bool)
+    r[0, 0, 0] = r[0, 0, 1] = r[0, 1, 0] = r[1, 0, 0] = r[1, 1, 2] = True
+    return O.RefinedBrickMesh(p, (3, 2, 2), r, H=0.5, deform_amp=amp)
+
+
+def hanging():
+    """round 2: operator, right-hand side, diagonal and 6 CG iterations on a 2:1 refined mesh (oracle path: resolve_hanging, RefinedBrickMesh)"""
+    out = {}
+    for p, amp in HANGING_CASES:
+        m = hanging_mesh(p, amp)
+        _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+        coef = O.merged_metric(m, N, D, w, O.kappa_step64)
+        c = m.constrained.astype(np.int64)
+
+        def A(s):
+            d = O.apply_cells(m, coef, N, D, s)
+            d[c] = s[c]
+            return d
+
+        b = O.assemble_rhs(m)
+        x, _, _ = O.cg_plain(A, b, 6)
+        k = f"p{p}_a{amp}"
+        out[k + "_masks"] = m.constraint_mask
+        out[k + "_vmult"] = A(O.deterministic_src(m.n_dofs, seed=300 + p))
+        out[k + "_rhs"] = b
+        out[k + "_diag"] = O.operator_diagonal(m, coef, N, D)
+        out[k + "_x"] = x
+    np.savez_compressed(os.path.join(HERE, "hanging_cases.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "hanging":
+        hanging()                       # (the round-1 files are left as they are)
+    else:
+        main()
+        hanging()

@@ -1386,6 +1386,27 @@ def test_hanging_nodes_on_general_two_level_meshes(pattern, p, quad, amp):
     assert rel(x.cpu().numpy(), xj) < TOL_CG
 
 
+def test_hanging_node_golden_fixtures():
+    """the committed outputs of tests/golden/hanging_cases.npz (operator, RHS, diagonal, 6 CG iterations on a staircase-refined mesh)
+    straight against the HIP path, without the oracle in between"""
+    from make_golden import HANGING_CASES, hanging_mesh
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hanging_cases.npz"))
+    for p, amp in HANGING_CASES:
+        m = hanging_mesh(p, amp)                       # mesh arrays only (inputs); expected outputs come from the file
+        k = f"p{p}_a{amp}"
+        assert np.array_equal(m.constraint_mask, z[k + "_masks"])
+        op = pkg.PoissonOperator(_hanging_namespace(m), 0, pkg.COEF_STEP64)
+        dst = op.initialize_dof_vector()
+        op.vmult(dst, dev(O.deterministic_src(m.n_dofs, seed=300 + p)))
+        assert rel(dst.cpu().numpy(), z[k + "_vmult"]) < TOL_OP
+        b = op.assemble_rhs()
+        assert rel(b.cpu().numpy(), z[k + "_rhs"]) < TOL_OP
+        assert rel(op.compute_diagonal().cpu().numpy(), z[k + "_diag"]) < 1e-13
+        x = op.initialize_dof_vector()
+        pkg.SolverCG(pkg.IterationNumberControl(6, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+        assert rel(x.cpu().numpy(), z[k + "_x"]) < TOL_CG
+
+
 # ------------------------------------------------------------------ edge cases
 def test_single_cell_and_tiny_meshes():
     """one cell (every DoF on the Dirichlet boundary except the interior ones), p = 1 and p = 8"""
