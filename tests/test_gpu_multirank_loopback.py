@@ -188,7 +188,8 @@ def test_refined_mesh_with_hanging_nodes_across_ranks(tmp_path, world, p, amp):
         assert abs(float(z["l2"]) - l2) < 1e-12 * l2
 
 
-def test_quadrant_partition_with_two_way_and_diagonal_neighbours(tmp_path):
+@pytest.mark.parametrize("layout", ["quadrants", "random"])
+def test_quadrant_partition_with_two_way_and_diagonal_neighbours(tmp_path, layout):
     """A conforming mesh cut into 2 x 2 quadrants in (x, y), four ranks: every rank has neighbours it both sends to and receives from, and
     ranks 0 and 3 share only an edge of DoFs -- halo plans the library's own slab generator never produces (it is what a
     p4est-style host hands over).  Same checks as above; the mask array is all zero (conforming), so the default kernels run."""
@@ -199,10 +200,16 @@ def test_quadrant_partition_with_two_way_and_diagonal_neighbours(tmp_path):
     m = pr.mesh
     n = p + 1
     cen = m.coords[m.l2g.astype(np.int64)].reshape(m.n_cells, -1, 3).mean(1)
-    cell_rank = (cen[:, 0] > 2.0).astype(int) + 2 * (cen[:, 1] > 2.0).astype(int)
-    assert sorted(np.bincount(cell_rank)) == [12, 12, 12, 12]
+    if layout == "quadrants":
+        cell_rank = (cen[:, 0] > 2.0).astype(int) + 2 * (cen[:, 1] > 2.0).astype(int)
+        assert sorted(np.bincount(cell_rank)) == [12, 12, 12, 12]
+    else:               # cells dealt out at random: every rank neighbours every other, hardly any interior cell, scattered ghost sets
+        cell_rank = np.random.default_rng(11).integers(0, world, m.n_cells)
     pieces = partition(m, cell_rank, world, owner_rule="alternate")
-    assert [pc["n_neighbors"] for pc in pieces] == [3, 2, 2, 3]      # (the DoFs of the common edge belong to rank 0 or 3: ranks 1 and 2 never talk)
+    if layout == "quadrants":
+        assert [pc["n_neighbors"] for pc in pieces] == [3, 2, 2, 3]  # (the DoFs of the common edge belong to rank 0 or 3: ranks 1 and 2 never talk)
+    else:
+        assert all(pc["n_neighbors"] == 3 for pc in pieces)
     assert any(pc["send_offsets"][k + 1] > pc["send_offsets"][k] and pc["recv_offsets"][k + 1] > pc["recv_offsets"][k]
                for pc in pieces for k in range(pc["n_neighbors"]))                       # a two-way neighbour exists
     for rk, pc in enumerate(pieces):
