@@ -898,7 +898,10 @@ def test_medium_size_against_c_oracle():
     (5, (73, 73, 73), 0, 0.03, 1, dict(cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1), 56),
     (7, (52, 52, 52), 1, 0.03, 1, dict(cell_block=(4, 2, 2), dof_numbering=1, cell_block_order=1), 56),
     (3, (122, 122, 122), 0, 0.03, 1, dict(cell_block=(8, 4, 4), dof_numbering=1, cell_block_order=1), 56),
-    (2, (184, 184, 184), 0, 0.0, 1, dict(cell_block=(8, 8, 4), dof_numbering=1, cell_block_order=1), 56)])
+    (2, (184, 184, 184), 0, 0.0, 1, dict(cell_block=(8, 8, 4), dof_numbering=1, cell_block_order=1), 56),
+    # maximum sizes: five times the headline problem on one GPU (513 922 401 DoFs, half the 2^30 range of the local 32-bit indices; 64-bit
+    # offsets into the 49 GB metric array); profiles/r2 holds a bench line at 1 003 003 001 DoFs
+    (4, (200, 200, 200), 0, 0.0, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56)])
 def test_full_size_properties(p, cells, quad, amp, km, kw, variant):
     """Size-independent properties at BASELINE scale: constants in the null space of the cell
     loop, symmetry, linearity; CG residual consistency.  The third case is the bench's mesh ordering
