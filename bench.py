@@ -65,20 +65,28 @@ def live_traffic(kernel, workload_args, timeout_s=90):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bp5_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", "python3",
+            # the program after `--` is the running interpreter itself (a real ELF binary: no shim that would exec under the profiler's preload)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", os.path.realpath(sys.executable),
                    os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained-iters", "0",
                    "--no-traffic-pass"] + workload_args
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                               timeout=timeout_s)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                rc = child.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)    # the profiler AND the python grandchild that holds the GPU (its own session: nothing else)
+                child.wait()
+                return None
             files = glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
                     if want in row["Kernel_Name"].replace(" ", "") and row.get("Counter_Name", counter) == counter]
             if not vals:
                 return None
             kib[counter] = sum(vals) / len(vals)
-        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -122,21 +130,42 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+PHASES = ["update", "gather_wait", "operator", "exchange", "reduce_local", "allreduce", "control", "iteration"]   # bp5.h BP5_PHASE_*
+SCHEDULES = {0: "none (one rank)", 1: "unsplit", 2: "boundary-first", 3: "three-phase"}                          # bp5_cg_result.exchange_schedule
+CONFIG_SIZES = {1: 367, 2: 184, 3: 122, 4: 92, 5: 73, 6: 61, 7: 52, 8: 46}    # BASELINE config 4: ~5e7 DoFs per degree
+
+
+def default_cell_block(p, cells_per_rank):
+    """Cell order / DoF numbering are the host's choice (the reference's MatrixFree::reinit reorders cells too): bricks sized for the
+    block kernel's LDS accumulator, parity-class order inside a brick, brick-major DoF numbering -> the library picks its deterministic
+    block kernel.  Small problems (config 2's 54^3; the 116x116x14.5 slab of one of 8 ranks): 4x4x2 bricks give the persistent
+    workgroups twice as many bricks to balance (profiles/r2: 0.427 vs 0.439 ms per iteration at 54^3).  p = 2, 5, 8: the atomic pencil
+    kernel is still ahead of the block kernel (profiles/r2) and gains 3-6 % from 8x8x8 parity-class bricks (p = 2: lexicographic)."""
+    small = cells_per_rank < 400000
+    return {1: (8, 8, 8), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (8, 8, 8), 6: (4, 4, 2), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="timed CG iterations (default 50; --config 1: 10)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--config", type=int, choices=[1, 2, 3, 4, 5], default=None,
+                    help="BASELINE.json configuration as ONE flag: 1 = p 2, 8^3 cells, 10 iterations (plumbing); 2 = p 4, 54^3 (1.02e7 DoFs), "
+                         "variable coefficient; 3 = p 4, 116^3 (1.0e8 DoFs; the default, what --gpus N splits); 4 = degree sweep p = 1..8 at ~5e7 "
+                         "DoFs (value = the degree of --degree, all eight under 'sweep'); 5 = p 6, 61^3, deformed mesh")
+    ap.add_argument("--degree", type=int, default=None)
     ap.add_argument("--cells", type=int, nargs=3, default=None,
                     help="cells per direction of the WHOLE problem (strong scaling) / per GPU (weak scaling); default: config 3 / 4 sizes")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the same problem split into N z-slabs (default, BASELINE config 3); weak = one such problem per GPU")
     ap.add_argument("--quadrature", choices=["gauss", "gll"], default="gauss")
     ap.add_argument("--coefficient", choices=["one", "step64"], default="step64")
-    ap.add_argument("--deform", type=float, default=0.0)
+    ap.add_argument("--deform", type=float, default=None)
     ap.add_argument("--variant", choices=["merged", "plain"], default="merged")
     ap.add_argument("--apply-variant", type=int, default=0)
+    ap.add_argument("--overlap", type=int, choices=[0, 1, 2], default=2,
+                    help="N > 1: halo-exchange schedule of the timed solve (bp5_mf_set_overlap): 0 unsplit, 1 boundary-first, 2 the library decides")
     ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6",
                     help="merged6: the reference's six stored planes per q-point (G=6, default); affine: per-cell metric + one scalar plane (G=1), affine meshes only")
     ap.add_argument("--cell-block", type=int, nargs=3, default=None,
@@ -149,12 +178,23 @@ def main():
     ap.add_argument("--no-traffic-pass", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only); the committed passes of "
                          "profiles/*/traffic.json are quoted instead.  Needed under an outer profiler.")
+    ap.add_argument("--no-exchange-ab", action="store_true",
+                    help="N > 1: skip the diagnostic solves after the timed region (unsplit vs boundary-first exchange, phase stamps)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="control-flow rehearsal of an N > 1 run on ONE GPU (tests only): every rank on cuda:0, torch.distributed over gloo, "
                          "needs BP5_LIB = libbp5_loopback.so (RCCL refuses two ranks on one device); the JSON line is marked, its numbers mean nothing")
     ap.add_argument("--dry-run", action="store_true",
                     help="host only (no GPU, no process group): every rank builds its slab of the mesh and prints its partition as one JSON line")
     args = ap.parse_args()
+    # BASELINE configurations as one flag each (explicit flags still win)
+    cfg = {1: dict(degree=2, cells=[8, 8, 8], steps=10, deform=0.0), 2: dict(degree=4, cells=[54, 54, 54], deform=0.0),
+           3: dict(degree=4, cells=[116, 116, 116], deform=0.0), 4: dict(deform=0.0), 5: dict(degree=6, cells=[61, 61, 61], deform=0.05)}.get(args.config, {})
+    for k, v in cfg.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    args.degree = 4 if args.degree is None else args.degree
+    args.steps = 50 if args.steps is None else args.steps
+    args.deform = 0.0 if args.deform is None else args.deform
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -165,6 +205,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def die(stage, err):
+        """a rank-tagged, stage-tagged message before the non-zero exit: what a failed first multi-GPU run needs to be diagnosed from its log"""
+        sys.stderr.write(f"[bench rank {rank}/{world} local_rank {local_rank}] FAILED in {stage}: {type(err).__name__}: {err}\n")
+        sys.stderr.flush()
+        os._exit(3)   # (no atexit collectives: the other ranks may be stuck in theirs)
+
     if args.rehearsal:
         if not os.environ.get("BP5_LIB", "").endswith("libbp5_loopback.so"):
             raise SystemExit("--rehearsal needs BP5_LIB=.../libbp5_loopback.so")
@@ -174,52 +221,63 @@ def main():
     comm = None
     if not args.dry_run:
         import torch
-        torch.cuda.set_device(local_rank)
+        try:
+            torch.cuda.set_device(local_rank)
+        except Exception as e:   # noqa: BLE001
+            die(f"torch.cuda.set_device({local_rank}) [visible devices: {torch.cuda.device_count()}]", e)
     if world > 1 and not args.dry_run:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearsal:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
+        try:
+            if args.rehearsal:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        except Exception as e:   # noqa: BLE001
+            die("torch.distributed.init_process_group (rendezvous / RCCL bootstrap of torch's own communicator)", e)
+        try:
+            comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
+        except Exception as e:   # noqa: BLE001
+            die("bp5_comm_create (ncclCommInitRank of the library's communicator; the unique id travels through torch.distributed)", e)
 
+    t_setup0 = time.perf_counter()
     p = args.degree
     # p = 4: the headline size (config 3: 116^3 cells, 100 544 625 DoFs); other degrees: config 4 (~5e7 DoFs)
-    n1 = {1: 367, 2: 184, 3: 122, 4: 116, 5: 73, 6: 61, 7: 52, 8: 46}[p]
+    n1 = {**CONFIG_SIZES, 4: 92 if args.config == 4 else 116}[p]
     base = tuple(args.cells) if args.cells else (n1, n1, n1)
     strong = args.scaling == "strong"
     cells = base if strong else (base[0], base[1], base[2] * world)   # z-slabs either way
     quad = pkg.QUAD_GAUSS if args.quadrature == "gauss" else pkg.QUAD_GLL
     km = pkg.COEF_STEP64 if args.coefficient == "step64" else pkg.COEF_ONE
+    G = 6 if args.geometry == "merged6" else 1
+    Solver = pkg.SolverCGFullMerge if args.variant == "merged" else pkg.SolverCG
+    precond = pkg.DiagonalMatrix()
 
-    # cell order / DoF numbering are the host's choice (the reference's MatrixFree::reinit reorders cells too): bricks of
-    # 4x4x4 cells, parity-class order inside a brick, brick-major DoF numbering -> the library picks its block kernel
-    # (p >= 5: the atomic pencil kernel gains 3-6 % from 8x8x8 parity-class bricks, profiles/r1 g_sweep_order_degrees.txt)
-    # small problems (config 2's 54^3; the 116x116x14.5 slab of one of 8 ranks): 4x4x2 bricks give the persistent workgroups twice
-    # as many bricks to balance (profiles/r2: 0.427 vs 0.439 ms per iteration at 54^3)
-    small = base[0] * base[1] * base[2] // (world if strong else 1) < 400000
-    # p = 1, 3, 6, 7: bricks sized for the deterministic block kernel (profiles/r2 configs: +9 % at p = 1, +29 % at p = 3, +5 % at p = 7, on
-    # par at p = 6 with the even-odd contractions); p = 5, 8: the atomic pencil kernel is still ahead of it and gains 3-6 % from 8x8x8
-    # parity-class bricks; p = 2: lexicographic
-    default_block = {1: (8, 8, 8), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (8, 8, 8), 6: (4, 4, 2), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
-    block = tuple(args.cell_block) if args.cell_block else default_block
-    blocked = all(b > 0 for b in block)
-    mesh = pkg.BrickMesh(p, cells, h=1.0 / cells[0], deform_amp=args.deform, rank=rank, n_ranks=world,
-                         cell_block=block if blocked else (0, 0, 0), dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0)
+    def build(p_, cells_, block_=None):
+        """mesh of this rank + operator (host work: mesh generation, index plans, upload; device: the merged metric)"""
+        blk = tuple(block_) if block_ else default_cell_block(p_, cells_[0] * cells_[1] * cells_[2] // (world if strong else 1))
+        blocked_ = all(b > 0 for b in blk)
+        mesh_ = pkg.BrickMesh(p_, cells_, h=1.0 / cells_[0], deform_amp=args.deform, rank=rank, n_ranks=world,
+                              cell_block=blk if blocked_ else (0, 0, 0), dof_numbering=1 if blocked_ else 0, cell_block_order=1 if blocked_ else 0)
+        return mesh_, blk, blocked_
+
+    mesh, block, blocked = build(p, cells, args.cell_block)
     if args.dry_run:
         print(json.dumps({"rank": rank, "world": world, "scaling": args.scaling, "cells": list(cells), "n_cells": int(mesh.n_cells),
                           "n_interior_cells": int(mesh.n_interior_cells), "n_owned": int(mesh.n_owned), "n_ghost": int(mesh.n_ghost),
                           "n_global_dofs": int(mesh.n_global_dofs), "neighbors": [int(r) for r in mesh.neighbor_rank]}), flush=True)
         return
-    G = 6 if args.geometry == "merged6" else 1
-    op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
-                             geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
-    op.mf_data.set_apply_variant(args.apply_variant)
-    b = op.assemble_rhs()
-    x = op.initialize_dof_vector()
-    Solver = pkg.SolverCGFullMerge if args.variant == "merged" else pkg.SolverCG
-    precond = pkg.DiagonalMatrix()
+    try:
+        op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
+                                 geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
+        op.mf_data.set_apply_variant(args.apply_variant)
+        op.mf_data.set_overlap(args.overlap)
+        b = op.assemble_rhs()
+        x = op.initialize_dof_vector()
+        torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001
+        die("operator set-up (bp5_mf_create / merged metric / RHS with compress(add): the FIRST halo exchange of the run)", e)
+    setup_s = time.perf_counter() - t_setup0
 
     def barrier():
         torch.cuda.synchronize()
@@ -228,24 +286,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def max_over_ranks(dt):
+    def reduce_ranks(v, how):
         if world == 1:
-            return dt
+            return v
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearsal else f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([float(v)], dtype=torch.float64, device="cpu" if args.rehearsal else f"cuda:{local_rank}")
+        dist.all_reduce(tt, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[how])
         return float(tt.item())
 
-    # warm-up
-    Solver(pkg.IterationNumberControl(max(args.warmup, 1), 0.0), profile=True).solve(op, x, b, precond)
-    barrier()
-    ctl = pkg.IterationNumberControl(args.steps, 0.0)
-    solver = Solver(ctl, profile=True)
-    barrier()
-    t0 = time.perf_counter()
-    solver.solve(op, x, b, precond)
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    def timed_solve(iters, op_=None, x_=None, b_=None, profile=True):
+        """one solve of exactly `iters` iterations between barrier + synchronize pairs; wall clock, max over ranks"""
+        op_, x_, b_ = op if op_ is None else op_, x if x_ is None else x_, b if b_ is None else b_
+        ctl_ = pkg.IterationNumberControl(iters, 0.0)
+        sv = Solver(ctl_, profile=profile)
+        barrier()
+        t0_ = time.perf_counter()
+        sv.solve(op_, x_, b_, precond)
+        barrier()
+        return ctl_, reduce_ranks(time.perf_counter() - t0_, "max")
+
+    # warm-up: also the first solve with its gather / scatter-add groups and all-reduces
+    try:
+        Solver(pkg.IterationNumberControl(max(args.warmup, 1), 0.0), profile=True).solve(op, x, b, precond)
+        barrier()
+    except Exception as e:   # noqa: BLE001
+        die("warm-up solve (first RCCL send/recv groups of the operator and first 7-double all-reduce)", e)
+    ctl, dt = timed_solve(args.steps)
     iters = ctl.last_step()
     n_global = int(mesh.n_global_dofs)
     value = n_global * iters / dt
@@ -254,28 +320,53 @@ def main():
     # around each, the BEST repetition is reported.  Minutes-long runs clock ~5 % below short bursts (profiles/r1 j_*).
     sustained = None
     if args.sustained_iters > 0 and args.sustained_reps > 0:
-        best, sctl = 0.0, pkg.IterationNumberControl(args.sustained_iters, 0.0)
-        ssolver = Solver(sctl)
+        best = 0.0
         for _ in range(args.sustained_reps):
-            barrier()
-            t0 = time.perf_counter()
-            ssolver.solve(op, x, b, precond)
-            barrier()
-            sdt = max_over_ranks(time.perf_counter() - t0)
+            sctl, sdt = timed_solve(args.sustained_iters, profile=False)
             best = max(best, n_global * sctl.last_step() / sdt)
         sustained = {"value": best, "unit": "DoF/s", "iterations": args.sustained_iters, "repetitions": args.sustained_reps,
                      "protocol": "reference: best of n repetitions of one solve, wall clock incl. device sync (bp5/step-64.cu:457-463,724-730)"}
 
+    # every rank decides fused / unfused from its own brick plan: agree before anything collective branches on it
+    fused_all = bool(reduce_ranks(1.0 if ctl.dot_products_fused else 0.0, "min"))
+    fused_any = bool(reduce_ranks(1.0 if ctl.dot_products_fused else 0.0, "max"))
+
     # the bare operator kernel in the same run (when the timed solve fused the dot products into it): a short solve with the
     # separate dot-product kernel, so that the operator-only roofline figure of SURVEY 8(d) can be read off the same box
     unfused_ms = None
-    if ctl.dot_products_fused:
+    if fused_all:
         op.mf_data.set_cg_fusion(False)
-        uctl = pkg.IterationNumberControl(10, 0.0)
-        Solver(uctl, profile=True).solve(op, x, b, precond)
-        barrier()
+        uctl, _ = timed_solve(10)
         unfused_ms = uctl.apply_ms_avg
         op.mf_data.set_cg_fusion(True)
+
+    # N > 1 diagnostics: the same solve in both exchange schedules, each once plainly timed and once with phase stamps (HIP events at
+    # the phase boundaries of every iteration on the solver's stream; the stamps cost a few us each, so the stamped run is not the timed
+    # one).  One driver run then tells how much of an iteration is kernels, exposed exchange, and all-reduce -- per rank extremes.
+    exchange_ab = None
+    if world > 1 and not args.no_exchange_ab and args.variant == "merged":
+        exchange_ab = {}
+        k_ab = max(10, min(args.steps, 40))
+        for mode, name in ((0, "unsplit"), (1, "boundary_first")):
+            try:
+                op.mf_data.set_overlap(mode)
+                timed_solve(3)
+                actl, adt = timed_solve(k_ab, profile=False)
+                pctl, _ = timed_solve(min(k_ab, 32), profile=2)
+                entry = {"ms_per_iteration": adt / max(actl.last_step(), 1) * 1e3, "iterations": actl.last_step(),
+                         "schedule_rank0": SCHEDULES.get(actl.exchange_schedule, "?"), "dot_products_fused_rank0": bool(actl.dot_products_fused),
+                         "phases_ms_max_over_ranks": {}, "phases_ms_min_over_ranks": {}}
+                for i, ph in enumerate(PHASES):
+                    entry["phases_ms_max_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "max")
+                    entry["phases_ms_min_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "min")
+                exchange_ab[name] = entry
+            except Exception as e:   # noqa: BLE001
+                die(f"exchange A/B leg '{name}' (bp5_mf_set_overlap({mode}))", e)
+        op.mf_data.set_overlap(args.overlap)
+        exchange_ab["note"] = ("same problem, same kernels; unsplit = gather, one launch, scatter-add on the compute stream; boundary_first = "
+                               "ghost-touching bricks first, scatter-add on the communication stream under the interior bricks.  phases: HIP "
+                               "events on the solver's stream (exchange = exposed part incl. unpack; gather_wait = exposed part of the ghost "
+                               "gather that travels under the vector update)")
 
     # achievable-stream figure: device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
     import ctypes as C
@@ -294,6 +385,30 @@ def main():
     stream_copy_gbs = 16.0 * mesh.n_owned * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del ya, xa
 
+    # BASELINE config 4 as one line: the other degrees at their ~5e7-DoF sizes, one short solve each (N = 1)
+    sweep = None
+    if args.config == 4 and world == 1:
+        sweep = []
+        for q in range(1, 9):
+            if q == p and not args.cells:
+                r_q = mesh.n_cells * (q + 1) ** 3 / mesh.n_owned
+                sweep.append({"degree": q, "cells": list(cells), "dofs": n_global, "value": value, "ms_per_step": dt / max(iters, 1) * 1e3,
+                              "kernel": ctl.apply_kernel, "frac_of_hbm_peak": value * algorithmic_bytes_per_dof(q, mesh.n_cells, mesh.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
+                continue
+            nq = CONFIG_SIZES[q]
+            mq, _, _ = build(q, (nq, nq, nq))
+            oq = pkg.PoissonOperator(mq, quad, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
+            bq, xq = oq.assemble_rhs(), oq.initialize_dof_vector()
+            timed_solve(3, oq, xq, bq)
+            cq, dq = timed_solve(max(10, min(args.steps, 30)), oq, xq, bq)
+            vq = int(mq.n_global_dofs) * cq.last_step() / dq
+            sweep.append({"degree": q, "cells": [nq, nq, nq], "dofs": int(mq.n_global_dofs), "value": vq, "ms_per_step": dq / max(cq.last_step(), 1) * 1e3,
+                          "kernel": cq.apply_kernel, "dot_products_fused": bool(cq.dot_products_fused),
+                          "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
+            oq.mf_data.close()
+            del oq, bq, xq, mq
+            torch.cuda.empty_cache()
+
     if rank == 0:
         n_cells_local, n_dofs_local = mesh.n_cells, mesh.n_owned
         r = n_cells_local * (p + 1) ** 3 / n_dofs_local
@@ -302,16 +417,16 @@ def main():
         apply_s = ctl.apply_ms_avg * 1e-3
         ev = op.mf_data.get_apply_variant()
         key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}"
-        block_kernel = ev in (48, 49, 56, 60, 61)
-        # SolverCGFullMerge on the packed block kernel, one rank: the dot products of update_b (contract: "dot reads p,r,v",
+        block_kernel = ctl.apply_kernel.startswith("apply_block_kernel")
+        # SolverCGFullMerge on the packed block kernel: the dot products of update_b (contract: "dot reads p,r,v",
         # 24 B/DoF of the formula's 88) are formed inside the operator's write-out (reported by the solve itself)
         fused = bool(ctl.dot_products_fused)
         B_kernel = B_op + (24.0 if fused else 0.0)
         achieved = B_kernel * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
-        lpc = {1: 4, 2: 16, 3: 16, 4: 32, 5: 64, 6: 64, 7: 64, 8: 128}.get(p, 0)
-        coll = "true" if args.quadrature == "gll" else "false"
-        kname = f"apply_block_kernel<{p},{coll},{lpc},1,1337344>" if fused else \
-            {0: "apply_pencil_kernel", 10: "apply_team_kernel", 56: f"apply_block_kernel<{p},{coll},{lpc},1,288768>"}.get(ev, f"apply variant {ev}")
+        # what the launched kernel has to move for its own representation (block kernel: one packed u16 per cell-local DoF instead of the
+        # 4r of local_to_global; fused: r at the stored DoFs only -- p.v comes from the quadrature-point energy, v.v from LDS)
+        B_moved = (16.0 + 2.0 * r + G * 8.0 * r + (8.0 if fused else 0.0)) if block_kernel else B_kernel
+        kname = ctl.apply_kernel or f"apply variant {ev}"     # reported by the solve: the kernel it launched, as a profiler prints it
         tr = None
         if world == 1 and not args.no_traffic_pass and not args.rehearsal:
             wl = ["--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
@@ -330,17 +445,29 @@ def main():
             "config": {"workload": f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
+                       "baseline_config": args.config if args.config else (3 if (p == 4 and base == (116, 116, 116)) else None),
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world} ({args.scaling} scaling)",
-                       "cell_block": list(block) if blocked else None, "apply_variant": ev, "cg_dot_products_fused": fused},
+                       "cell_block": list(block) if blocked else None, "apply_variant": ev, "cg_dot_products_fused": fused,
+                       "cg_dot_products_fused_on_every_rank": fused_all, "cg_dot_products_fused_on_some_rank": fused_any,
+                       "exchange_schedule": SCHEDULES.get(ctl.exchange_schedule, "?"), "overlap_policy": args.overlap},
             "value_per_gpu": value / world,   # the reference's convention divides by the rank count (bp5/step-64.cu:457-461)
-            "roofline_cg": {"bytes_per_dof": B, "achieved_GBs_per_gpu": value / world * B / 1e9,
-                            "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS,
-                            "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": value / world * B / 1e9 / stream_copy_gbs},
+            "host_setup_s": setup_s,          # this rank: mesh generation, index plans, upload, merged metric, RHS (every rank does its own slab in parallel)
+            # whole iteration against the roofline, priced by the CONTRACT FORMULA of SURVEY 8(d) (16 + 4r + 48r + 88 B/DoF): a formula-based
+            # figure, not a measured bandwidth -- the fused iteration moves fewer bytes than the formula credits (2r index stream, 8 B instead
+            # of 24 B for the dot products), which is why frac_of_stream_copy can exceed 1; bytes_moved_per_dof prices what is really moved
+            "roofline_cg": {"basis": "contract formula (SURVEY 8d), not measured bytes", "bytes_per_dof": B,
+                            "achieved_GBs_per_gpu": value / world * B / 1e9, "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS,
+                            "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": value / world * B / 1e9 / stream_copy_gbs,
+                            # merged CG as implemented: update kernels 40 / 56 B/DoF alternating (the operator overwrites v: no v write, x every
+                            # second iteration) = 48 on average instead of the formula's 64; separate dot-product pass 24 when not fused
+                            "bytes_moved_per_dof": (B_moved + 48.0 + (0.0 if fused else 24.0)) if args.variant == "merged" else None,
+                            "frac_moved_of_hbm_peak": (value / world * (B_moved + 48.0 + (0.0 if fused else 24.0)) / 1e9 / HBM_PEAK_GBS) if args.variant == "merged" else None},
             # `achieved`: algorithmic bytes of ONE launch of the dominant kernel / its average duration (HIP events on the solver's
             # stream around that launch, inside the timed solve).  Unfused: one operator application, B_op x DoFs of this rank.
             # Fused (default at p = 4 on bricks): the same kernel also does the solver's dot-product pass, so its algorithmic
             # bytes are B_op + 24 B/DoF (the contract formula's "dot reads p, r, v"); `frac_operator_only` prices the same
-            # duration against B_op alone.  `operator_ms`: zero-fill (atomic kernels) + cell kernel + combine pass.
+            # duration against B_op alone, `frac_moved` against the bytes this kernel's representation has to move.
+            # `operator_ms`: zero-fill (atomic kernels) + cell kernel + combine pass.
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["traffic_bytes"] if tr else None,
@@ -349,6 +476,8 @@ def main():
                          "bytes_per_dof": B_kernel, "avg_launch_ms": ctl.apply_ms_avg, "launches": ctl.apply_launches,
                          "operator_ms": ctl.operator_ms_avg,
                          "frac_operator_only": B_op * n_dofs_local / apply_s / 1e9 / HBM_PEAK_GBS if apply_s > 0 else 0.0,
+                         "bytes_moved_per_dof": B_moved,
+                         "frac_moved": B_moved * n_dofs_local / apply_s / 1e9 / HBM_PEAK_GBS if apply_s > 0 else 0.0,
                          # the same operator kernel WITHOUT the fused dot products (10 untimed iterations after the timed region): the
                          # SURVEY 8(d) operator-only figure, B_op x DoFs / its average launch duration
                          "operator_kernel_unfused": ({"avg_launch_ms": unfused_ms, "bytes_per_dof": B_op,
@@ -357,7 +486,7 @@ def main():
                                                  f" B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)"),
                          # what this kernel has to move for its own representation (the contract formula credits I = 1 and 24 B for the dots)
                          "bytes_moved_formula": ((f"16 + 2r + G*8r" + (" + 8 [r at the stored DoFs; p.v comes from the quadrature-point energy, v.v from LDS]" if fused else "") +
-                                                  f" = {16 + 2 * r + G * 8 * r + (8 if fused else 0):.1f} B/DoF: one packed u16 (run, offset) per cell-local DoF "
+                                                  f" = {B_moved:.1f} B/DoF: one packed u16 (run, offset) per cell-local DoF "
                                                   f"instead of the 4r of local_to_global") if block_kernel else
                                                  f"16 + 4r + G*8r = {B_op:.1f} B/DoF (local_to_global is read)")},
         }
@@ -366,6 +495,10 @@ def main():
             out["metric"] = "REHEARSAL (not a measurement): " + out["metric"]
         if sustained:
             out["sustained"] = sustained
+        if exchange_ab:
+            out["exchange_ab"] = exchange_ab
+        if sweep:
+            out["sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(mesh, p, quad, km, args.cpu_budget, max(args.steps, 2))
         print(json.dumps(out), flush=True)

@@ -82,7 +82,8 @@ class CGParams(C.Structure):
 
 class CGResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("initial_residual", C.c_double), ("solve_ms", C.c_double),
-                ("apply_ms_avg", C.c_double), ("apply_launches", C.c_int), ("operator_ms_avg", C.c_double), ("dot_products_fused", C.c_int)]
+                ("apply_ms_avg", C.c_double), ("apply_launches", C.c_int), ("operator_ms_avg", C.c_double), ("dot_products_fused", C.c_int),
+                ("exchange_schedule", C.c_int), ("apply_kernel", C.c_char * 96), ("phase_ms", C.c_double * 8)]
 
 
 VMULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # bp5_vmult_fn(ctx, dst, src)

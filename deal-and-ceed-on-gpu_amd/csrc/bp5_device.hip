@@ -174,6 +174,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
   for (hipEvent_t e : mf->ev_pool) hipEventDestroy(e);
+  for (hipEvent_t e : mf->phase.ev) hipEventDestroy(e);
   for (hipEvent_t e : mf->ev_solve) if (e) hipEventDestroy(e);
   for (hipEvent_t e : mf->ev_halo) if (e) hipEventDestroy(e);
   if (mf->comm_stream) { hipStreamSynchronize(mf->comm_stream); hipStreamDestroy(mf->comm_stream); }
@@ -494,6 +495,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       BP5_TRY(upload(&dp.runs, runs.data(), runs.size()));
     }
     dp.n_shared = (uint32_t)h.sh_dof.size();
+    dp.n_shared_owned = (uint32_t)(std::lower_bound(h.sh_dof.begin(), h.sh_dof.end(), mf->n_owned) - h.sh_dof.begin());
     if (dp.n_shared) { // run-length form of the shared-DoF CSR for combine_runs_kernel
       std::vector<uint32_t> start, dof0, soff, slots, tile;
       const size_t ns = h.sh_dof.size();
@@ -544,19 +546,30 @@ int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
   return BP5_OK;
 }
 
-int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
+int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window)
 {
   if (!dp->n_shared) return BP5_OK;
   if (mf->fuse.on && !(set && dp->cr_tile && !mf->combine_csr)) return fail(BP5_ERR_INVALID, "fused dot products need the run-length combine pass in overwrite mode");
-  if (mf->prof_mark) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
-  const dim3 cg((dp->n_shared + 255) / 256), cgt((dp->n_shared + COMBINE_TILE - 1) / COMBINE_TILE); // CSR kernel / run kernel (pairs)
+  if (window != COMBINE_ALL && !(dp->cr_tile && !mf->combine_csr)) return fail(BP5_ERR_INVALID, "combine windows need the run-length combine pass");
+  if (mf->prof_mark && window != COMBINE_GHOST) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
+  const dim3 cg((dp->n_shared + 255) / 256); // CSR kernel
   if (dp->cr_tile && !mf->combine_csr) {
     CombineRuns cr{};
     cr.start = dp->cr_start; cr.dof0 = dp->cr_dof0; cr.soff = dp->cr_soff; cr.slots = dp->cr_slots; cr.tile_run = dp->cr_tile;
     cr.n_shared = dp->n_shared;
-    if (mf->fuse.on) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
+    // tiles of the window: the shared DoFs are listed in ascending order, owned ones first
+    const uint32_t all_tiles = (dp->n_shared + COMBINE_TILE - 1) / COMBINE_TILE;
+    cr.tile0 = window == COMBINE_GHOST ? dp->n_shared_owned / COMBINE_TILE : 0u;
+    const uint32_t tile1 = window == COMBINE_OWNED ? (dp->n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE : all_tiles;
+    cr.dof_lo = window == COMBINE_GHOST ? mf->n_owned : 0u;
+    cr.dof_hi = window == COMBINE_OWNED ? mf->n_owned : 0xffffffffu;
+    if (tile1 <= cr.tile0) return BP5_OK; // no row in the window
+    const dim3 cgt(tile1 - cr.tile0);
+    if (mf->fuse.on && window != COMBINE_GHOST) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
+      // (ghost rows never enter the dot products: their window takes the plain kernel below)
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = cgt.x; cr.cg_state = mf->d_st;
+      if (mf->fuse.n_cols + 1024u + 8u > (uint32_t)PARTIAL_STRIDE) return fail(BP5_ERR_UNSUPPORTED, "no partial-sum columns left for the combine pass");
       const uint32_t grid = std::min<uint32_t>(cgt.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u); // 1024 columns stay free for the exchange
       // pairs of consecutive ordinals pay on long passes; short ones (config 2, the strong-scaling ranks) are latency-bound
       if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
@@ -565,7 +578,7 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set)
       mf->fuse.n_cols += grid;
       return BP5_OK;
     }
-    const bool pairs = dp->n_shared >= (8u << 20);
+    const bool pairs = dp->n_shared >= (8u << 20) && window != COMBINE_GHOST;
     if (set && pairs) hipLaunchKernelGGL((combine_runs_kernel<false, false, true>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     else if (set) hipLaunchKernelGGL((combine_runs_kernel<false, false, false>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     else if (pairs) hipLaunchKernelGGL((combine_runs_kernel<true, false, true>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
@@ -996,14 +1009,9 @@ extern "C" int bp5_halo_gather(bp5_mf *mf, double *v)
   return bp5_halo_gather_finish(mf, v);
 }
 // compress(add): ghost contributions travel back to the owners and are added; ghosts zeroed
-extern "C" int bp5_halo_scatter_add_start(bp5_mf *mf, double *v)
+static int scatter_exchange(bp5_mf *mf, double *v, bool on_comm_stream)
 {
-  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
-  if (mf->neighbors.empty()) return BP5_OK;
-  if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
-  HIP_TRY(hipSetDevice(mf->device));
-  BP5_TRY(halo_streams(mf));
-  mf->overlap_now = overlap_wanted(mf);
+  mf->overlap_now = on_comm_stream;
   hipStream_t cs = mf->overlap_now ? mf->comm_stream : mf->stream;
   if (mf->overlap_now) { // the ghost entries are complete at this point of the compute stream
     HIP_TRY(hipEventRecord(mf->ev_halo[2], mf->stream));
@@ -1018,6 +1026,15 @@ extern "C" int bp5_halo_scatter_add_start(bp5_mf *mf, double *v)
   NCCL_TRY(ncclGroupEnd());
   if (mf->overlap_now) HIP_TRY(hipEventRecord(mf->ev_halo[3], cs));
   return BP5_OK;
+}
+extern "C" int bp5_halo_scatter_add_start(bp5_mf *mf, double *v)
+{
+  if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
+  if (mf->neighbors.empty()) return BP5_OK;
+  if (!mf->comm) return fail(BP5_ERR_INVALID, "halo exchange needs bp5_mf_set_comm");
+  HIP_TRY(hipSetDevice(mf->device));
+  BP5_TRY(halo_streams(mf));
+  return scatter_exchange(mf, v, overlap_wanted(mf));
 }
 extern "C" int bp5_halo_scatter_add_finish(bp5_mf *mf, double *v)
 {
@@ -1088,12 +1105,12 @@ static int phases_range(bp5_mf *mf, const double *coef, const double *src, doubl
   if (c1 <= c0) return BP5_OK;
   return launch_apply(mf, coef, src, dst, c0, c1, ph.overwrite);
 }
-static int phases_end(bp5_mf *mf, double *dst, ApplyPhases &ph, int status)
+static int phases_end(bp5_mf *mf, double *dst, ApplyPhases &ph, int status, int window = COMBINE_ALL)
 {
   mf->defer_combine = false;
   mf->apply_variant = ph.user_variant;
   BP5_TRY(status);
-  return ph.block ? launch_combine(mf, ph.dp, dst, ph.set) : BP5_OK;
+  return ph.block ? launch_combine(mf, ph.dp, dst, ph.set, window) : BP5_OK;
 }
 // interior cells [0, split) run under the ghost gather, [split, n_interior) under the scatter-add; split on a brick boundary
 static uint32_t interior_split(const bp5_mf *mf)
@@ -1123,18 +1140,21 @@ static int apply_overlapped(bp5_mf *mf, const double *coef, double *src, double 
   if (st == BP5_OK) st = phases_range(mf, coef, src, dst, 0, split, ph);                 // under the gather
   if (st == BP5_OK) st = bp5_halo_gather_finish(mf, src);
   if (st == BP5_OK) st = phases_range(mf, coef, src, dst, mf->n_interior, mf->n_cells, ph); // cells that touch ghosts
-  // The ghost entries of dst are final only after the combine pass when the block kernel runs (ghost DoFs on brick faces
-  // go through the partial slab), so the block kernel sends them after the last range; the atomic kernels send them now,
-  // under the second part of the interior cells.
-  if (!ph.block) {
-    if (st == BP5_OK) st = bp5_halo_scatter_add_start(mf, dst);
+  // The atomic kernels have completed the ghost entries of dst once the ghost-touching cells are done; the block kernel needs the
+  // ghost ROWS of its combine pass on top (ghost DoFs on brick faces go through the partial slab): one small launch over the ghost
+  // window.  Either way the ghost contributions travel to their owners under the second part of the interior cells, and the block
+  // kernel's owned rows are combined after the last range -- every row once, in the order of the unsplit pass.
+  const bool ghost_rows = ph.block && ph.dp->n_shared && mf->n_ghost;                  // ghost rows (may) pass through the partial slab
+  if (ghost_rows && !(ph.dp->cr_tile && !mf->combine_csr)) { // (per-DoF CSR combine pass: no windows -- the ghost rows are final after the last range only)
     if (st == BP5_OK) st = phases_range(mf, coef, src, dst, split, mf->n_interior, ph);
     BP5_TRY(phases_end(mf, dst, ph, st));
-    return bp5_halo_scatter_add_finish(mf, dst);
+    return bp5_halo_scatter_add(mf, dst);
   }
+  if (st == BP5_OK && ghost_rows) st = launch_combine(mf, ph.dp, dst, ph.set, COMBINE_GHOST);
+  if (st == BP5_OK) st = bp5_halo_scatter_add_start(mf, dst);
   if (st == BP5_OK) st = phases_range(mf, coef, src, dst, split, mf->n_interior, ph);
-  BP5_TRY(phases_end(mf, dst, ph, st));
-  return bp5_halo_scatter_add(mf, dst);
+  BP5_TRY(phases_end(mf, dst, ph, st, ghost_rows ? COMBINE_OWNED : COMBINE_ALL));
+  return bp5_halo_scatter_add_finish(mf, dst);
 }
 extern "C" int bp5_apply_distributed(bp5_mf *mf, const double *coef, double *src, double *dst, int zero_dst)
 {
@@ -1215,6 +1235,16 @@ struct ApplyProfile {
   }
 };
 
+// profile == 2: stamp k of the iteration being profiled (bp5_cg_result.phase_ms)
+static int phase_mark(bp5_mf *mf, int k)
+{
+  auto &ph = mf->phase;
+  if (!ph.on || ph.it >= bp5_mf::PhaseProfile::MAX_ITERS) return BP5_OK;
+  HIP_TRY(hipEventRecord(ph.ev[(size_t)ph.it * bp5_mf::PhaseProfile::MARKS + k], mf->stream));
+  ph.recorded[ph.it] |= (uint8_t)(1u << k);
+  return BP5_OK;
+}
+
 // A.vmult(h, d) inside the solvers: dst already zero on entry when zeroed == true
 // n_cols != nullptr (CG on the packed block kernel, one rank's worth of cells): the operator's write-out and
 // combine pass also form the v-dependent dot products of update_b (bp5/solver.h:142-311) and apply the Dirichlet copy; the
@@ -1226,27 +1256,60 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
   const bool dist = mf->comm && !mf->neighbors.empty(); // halo exchange: whenever there are neighbours (tests: a self neighbour)
   const bool fusing = n_cols != nullptr;
   if (dist && fusing) {
-    // unsplit exchange + fused dot products: gather, ONE fused launch over all cells (p.v is a sum over cells, so it needs no
-    // owner bookkeeping; v.v, r.v, r.r run over owned DoFs), then the ghost contributions travel to their owners, whose
-    // unpack kernel corrects v.v and r.v for what it adds
+    // fused dot products across ranks: gather, fused launch(es) over all cells (p.v is a sum over cells, so it needs no owner
+    // bookkeeping; v.v, r.v, r.r run over owned DoFs), then the ghost contributions travel to their owners, whose unpack kernel
+    // corrects v.v and r.v for what it adds.
+    // Boundary-first schedule (mf->cg_split, the twin of overlap_communication_computation, bp5/step-64.cu:241,274): the bricks that
+    // touch ghost DoFs run FIRST, one small combine pass completes the ghost rows, the exchange starts on the communication stream and
+    // the interior bricks run underneath it; the owned rows are combined after the last brick.  Same kernels, same per-brick sums and
+    // the same combine order as the single launch: v is bitwise the same (the dot products are summed over a different column layout).
+    const bool split = mf->cg_split;
     if (mf->fuse.gather_in_flight) { mf->fuse.gather_in_flight = false; BP5_TRY(bp5_halo_gather_finish(mf, src)); } // started under the update kernel
     else BP5_TRY(bp5_halo_gather(mf, src));
+    BP5_TRY(phase_mark(mf, 2));
     BP5_TRY(prof.mark(0));
     BP5_TRY(prof.mark(1));
-    if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
     mf->fuse.on = true; mf->fuse.p = src; mf->fuse.r = fuse_r; mf->fuse.n_cols = 0;
-    int st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
-    const bool marked = prof.on && mf->prof_mark == nullptr;
-    mf->prof_mark = nullptr;
-    if (st == BP5_OK && !marked) st = prof.mark(2);
-    if (st == BP5_OK) st = prof.mark(3);
-    if (prof.on) prof.used += 4;
-    if (st == BP5_OK) st = bp5_halo_scatter_add(mf, dst); // (fuse.on: dot-product corrections + ghost zeroing inside)
+    int st = BP5_OK;
+    bool marked = false;
+    if (!split) {
+      if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
+      st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
+      marked = prof.on && mf->prof_mark == nullptr;
+      mf->prof_mark = nullptr;
+      if (st == BP5_OK && !marked) st = prof.mark(2);
+      if (st == BP5_OK) st = prof.mark(3);
+      if (prof.on) prof.used += 4;
+      if (st == BP5_OK) st = phase_mark(mf, 3);
+      if (st == BP5_OK) st = bp5_halo_scatter_add(mf, dst); // (fuse.on: dot-product corrections + ghost zeroing inside)
+    } else {
+      bp5_mf::DevPlan *dp = nullptr;
+      st = get_plan_raw(mf, -block_cpt(mf), &dp);
+      const int user_variant = mf->apply_variant;
+      mf->apply_variant = 56;    // every range takes the block kernel, however few bricks it holds
+      mf->defer_combine = true;  // one combine pass per window, launched here
+      if (st == BP5_OK && mf->n_interior < mf->n_cells) {
+        st = launch_apply(mf, coef, src, dst, mf->n_interior, mf->n_cells, true); // bricks that touch ghosts
+        if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+      }
+      if (st == BP5_OK) st = halo_streams(mf);
+      if (st == BP5_OK) st = scatter_exchange(mf, dst, true); // send the ghost rows / post the receives: under the interior bricks
+      if (st == BP5_OK && mf->n_interior) st = launch_apply(mf, coef, src, dst, 0, mf->n_interior, true);
+      mf->defer_combine = false;
+      mf->apply_variant = user_variant;
+      if (st == BP5_OK) st = prof.mark(2); // (the profile brackets both brick launches + the ghost-row combine)
+      if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, mf->n_ghost ? COMBINE_OWNED : COMBINE_ALL);
+      if (st == BP5_OK) st = prof.mark(3);
+      if (prof.on) prof.used += 4;
+      if (st == BP5_OK) st = phase_mark(mf, 3);
+      if (st == BP5_OK) st = bp5_halo_scatter_add_finish(mf, dst);
+    }
     *n_cols = mf->fuse.n_cols;
     const bool ghosts_zeroed = mf->fuse.ghosts_zeroed;
     mf->fuse = bp5_mf::Fuse{};
+    mf->defer_combine = false;
     BP5_TRY(st);
-    if (!ghosts_zeroed) BP5_TRY(bp5_halo_zero_ghosts(mf, src)); // (a rank that owns no interface DoFs launched no unpack kernel)
+    if (!ghosts_zeroed) BP5_TRY(bp5_halo_zero_ghosts(mf, src)); // (a rank that owns no interface DoFs launched no unpack kernel; dst: scatter_add_finish)
     // no Dirichlet copy: the write-out stored v = p on this rank's Dirichlet rows and the unpack kernel leaves them alone
     return BP5_OK;
   }
@@ -1315,6 +1378,17 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     const size_t want = 4 * (size_t)std::min(prm->max_iter, ApplyProfile::MAX_PROFILED);
     while (mf->ev_pool.size() < want) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); mf->ev_pool.push_back(e); }
   }
+  {
+    auto &ph = mf->phase;
+    ph.on = prm->profile == 2 && prm->variant == BP5_CG_MERGED;
+    ph.it = 0;
+    if (ph.on) {
+      const size_t want = (size_t)bp5_mf::PhaseProfile::MAX_ITERS * bp5_mf::PhaseProfile::MARKS;
+      while (ph.ev.size() < want) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ph.ev.push_back(e); }
+      ph.recorded.assign(bp5_mf::PhaseProfile::MAX_ITERS, 0);
+    }
+  }
+  struct PhaseGuard { bp5_mf *m; ~PhaseGuard() { m->phase.on = false; } } phase_guard{mf};
   const hipEvent_t ev0 = mf->ev_solve[0], ev1 = mf->ev_solve[1];
   // h = A d.  dst is fully defined by the call (the reference zeroes it in update_a* for its atomic scatter)
   auto vmult = [&](double *src, double *dst, const double *fuse_r, uint32_t *n_cols) -> int {
@@ -1342,21 +1416,30 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   int status = BP5_OK;
   // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank (merged solver: and D == 1;
   // the plain solver takes only d.h = the quadrature-point energy from the kernel, which no preconditioner enters).
-  // Across ranks the fused iteration uses the unsplit exchange: it saves a pass over p, r, v (24 B/DoF) where the 3-phase split would
-  // hide one DoF plane each way, so under the automatic overlap policy (2) fusion wins at every slab size; only an explicit
-  // bp5_mf_set_overlap(1) keeps the split schedule (and with it the separate dot-product kernel).
+  // Across ranks the fused iteration keeps its dot products in BOTH exchange schedules: unsplit (gather, one launch, scatter-add on the
+  // compute stream) or boundary-first (bp5_mf_set_overlap 1, or 2 = automatic when the ghost-touching bricks are a minority: they run
+  // first, their rows travel to the owners on the communication stream under the interior bricks; solver_vmult).
   const bool dist_solve = mf->comm && !mf->neighbors.empty();
-  if (!user && mf->cg_fusion && (plain || !diag) && !(dist_solve && mf->overlap == 1) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
+  bool split = false;
+  if (!user && mf->cg_fusion && (plain || !diag) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
       effective_variant(mf, 0, mf->n_cells) == 56) {
     bp5_mf::DevPlan *dp = nullptr;
     BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));
     fused_dots = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);
+    if (fused_dots && dist_solve) {
+      uint32_t b0_, b1_;
+      const bool possible = !mf->h_block_off.empty() && (mf->n_interior == 0 || mf->n_interior == mf->n_cells || block_aligned(mf, 0, mf->n_interior, &b0_, &b1_));
+      const bool pays = (uint64_t)mf->n_interior >= 2ull * (mf->n_cells - mf->n_interior); // ghost-touching bricks: at most a third of the cells
+      split = possible && (mf->overlap == 1 || (mf->overlap == 2 && pays));
+      if (mf->overlap == 1 && !split) fused_dots = false; // explicit overlap on a mesh that cannot run boundary-first: 3-phase schedule, separate dot products
+    }
   }
-  struct OverlapGuard { // the fused exchange stays on the compute stream whatever the slab size
+  struct OverlapGuard { // the fused exchanges choose their streams themselves (solver_vmult), whatever the slab size
     bp5_mf *m; int saved;
-    ~OverlapGuard() { m->overlap = saved; }
+    ~OverlapGuard() { m->overlap = saved; m->cg_split = false; }
   } overlap_guard{mf, mf->overlap};
   if (fused_dots && dist_solve) mf->overlap = 0;
+  mf->cg_split = split;
   // one rank, separate dot-product kernel: the two small launches around an operator that scatters with atomics fold into their
   // neighbours -- the update kernel stores the zeros the operator needs in h / v (it holds the values in registers for the last time),
   // the dot-product kernel applies the Dirichlet copy while it reads both vectors (bitmap of the Dirichlet DoFs)
@@ -1450,23 +1533,31 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     int it = 1;
     for (; it <= prm->max_iter; ++it) {
       const int mode = it == 1 ? 0 : it % 2 == 0 ? 1 : 2;
+      BP5_TRY(phase_mark(mf, 0));
       if (early_gather) { BP5_TRY(gather_under_update(mode)); mf->fuse.gather_in_flight = true; }
       launch_update(mode);
       KERNEL_CHECK();
+      BP5_TRY(phase_mark(mf, 1));
       if (fused) {
         uint32_t n_cols = 0;
         BP5_TRY(vmult(d, h, g, &n_cols));
+        BP5_TRY(phase_mark(mf, 4));
         hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_R0, mf->d_st);
       } else {
         BP5_TRY(folded_vmult(d, h)); // (h: zeroed by cgm_init_kernel before the first, by the update kernel before every later application)
+        BP5_TRY(phase_mark(mf, 4));
         hipLaunchKernelGGL(cgm_dots_kernel, dim3(grid2), dim3(VB), 0, s, d, g, h, diag, n, mf->d_st, mf->d_partials,
                            fold_small ? (const uint32_t *)mf->d_constrained_bits : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, grid2, mf->d_sc + SC_R0, mf->d_st);
       }
       KERNEL_CHECK();
+      BP5_TRY(phase_mark(mf, 5));
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
+      BP5_TRY(phase_mark(mf, 6));
       hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
       KERNEL_CHECK();
+      BP5_TRY(phase_mark(mf, 7));
+      if (mf->phase.on) ++mf->phase.it;
       if (check > 0 && it % check == 0 && it < prm->max_iter) {
         BP5_TRY(poll_state(mf));
         if (mf->h_st[ST_DONE]) break;
@@ -1491,6 +1582,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   res->apply_ms_avg = res->operator_ms_avg = 0.0;
   res->apply_launches = prof.used / 4;
   res->dot_products_fused = fused_dots ? 1 : 0;
+  res->exchange_schedule = !dist_solve ? 0 : split ? 2 : fused_dots ? 1 : overlap_wanted(mf) ? 3 : 1;
   if (prof.on && prof.used) {
     double tot = 0.0, tot_op = 0.0;
     for (int k = 0; k < prof.used; k += 4) {
@@ -1502,6 +1594,36 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     }
     res->apply_ms_avg = tot / (prof.used / 4);
     res->operator_ms_avg = tot_op / (prof.used / 4);
+  }
+  memset(res->apply_kernel, 0, sizeof(res->apply_kernel));
+  if (!user) strncpy(res->apply_kernel, mf->last_apply_kernel, sizeof(res->apply_kernel) - 1);
+  for (double &v : res->phase_ms) v = 0.0;
+  if (mf->phase.on) { // averages over the stamped iterations after the first (whose update kernel is the cheap update_a0)
+    using PP = bp5_mf::PhaseProfile;
+    const int n_it = std::min(mf->phase.it, (int)PP::MAX_ITERS);
+    int counted = 0;
+    for (int i = n_it > 1 ? 1 : 0; i < n_it; ++i) {
+      const uint8_t rec = mf->phase.recorded[i];
+      const uint8_t need = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 7);
+      if ((rec & need) != need) continue;
+      auto ms = [&](int a, int b, double &out) -> int {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, mf->phase.ev[(size_t)i * PP::MARKS + a], mf->phase.ev[(size_t)i * PP::MARKS + b]));
+        out += t;
+        return BP5_OK;
+      };
+      const bool g = rec & (1u << 2), x = rec & (1u << 3);
+      BP5_TRY(ms(0, 1, res->phase_ms[BP5_PHASE_UPDATE]));
+      if (g) BP5_TRY(ms(1, 2, res->phase_ms[BP5_PHASE_GATHER_WAIT]));
+      BP5_TRY(ms(g ? 2 : 1, x ? 3 : 4, res->phase_ms[BP5_PHASE_OPERATOR]));
+      if (x) BP5_TRY(ms(3, 4, res->phase_ms[BP5_PHASE_EXCHANGE]));
+      BP5_TRY(ms(4, 5, res->phase_ms[BP5_PHASE_REDUCE]));
+      BP5_TRY(ms(5, 6, res->phase_ms[BP5_PHASE_ALLREDUCE]));
+      BP5_TRY(ms(6, 7, res->phase_ms[BP5_PHASE_CONTROL]));
+      BP5_TRY(ms(0, 7, res->phase_ms[BP5_PHASE_ITERATION]));
+      ++counted;
+    }
+    if (counted) for (double &v : res->phase_ms) v /= counted;
   }
   if (mf->h_st[ST_BREAKDOWN]) status = fail(BP5_ERR_BREAKDOWN, "CG breakdown: p.Ap is zero or NaN");
   return status;

@@ -88,6 +88,8 @@ struct bp5_mf {
   bool overlap_now = false;   // the decision for the exchange in flight (set by *_start)
   bool cg_fusion = true;      // SolverCGFullMerge: dot products inside the block kernel's write-out when the plan allows
   bool defer_combine = false; // block kernel on cell ranges: partial slab now, ONE combine pass after the last range
+  bool cg_split = false;      // set by a solve with fused dot products across ranks: boundary-first schedule -- the bricks run in two
+                              // launches (ghost-touching ones first), one combine pass per window, the exchange under the interior bricks
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
@@ -99,6 +101,15 @@ struct bp5_mf {
   std::vector<hipEvent_t> ev_pool;
   hipEvent_t ev_solve[2] = {nullptr, nullptr}; // start / stop of a solve (owned by the handle: no leak on error paths)
   hipEvent_t prof_mark = nullptr; // profiling: recorded once before the combine pass (= end of the dominant kernel)
+  char last_apply_kernel[96] = ""; // the operator kernel launched last, named as a profiler prints it (bp5_cg_result.apply_kernel)
+  // profile == 2: stamps at the phase boundaries of every merged-CG iteration (bp5_cg_result.phase_ms)
+  struct PhaseProfile {
+    static constexpr int MARKS = 8, MAX_ITERS = 64;
+    std::vector<hipEvent_t> ev;   // [MAX_ITERS][MARKS]
+    std::vector<uint8_t> recorded; // [MAX_ITERS] bit k: mark k recorded
+    bool on = false;
+    int it = 0;                   // iteration being stamped (0-based); stamps beyond MAX_ITERS are dropped
+  } phase;
   // team plans of the team-assembled kernel, keyed by cells per team
   std::vector<uint32_t> h_l2g;
   struct DevPlan {
@@ -114,6 +125,7 @@ struct bp5_mf {
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t *> *wg_blocks = nullptr;
     uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
+    uint32_t n_shared_owned = 0; // shared DoFs are listed in ascending order: ordinals [0, n_shared_owned) are owned DoFs, the rest ghosts
     bool covers_all = false;
   };
   std::vector<bool> h_constrained;   // per local DoF: Dirichlet DoF (run tables carry the flag)
@@ -151,7 +163,10 @@ inline int upload(T **dptr, const T *host, size_t count)
 // -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
 int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block = 64);
 int get_plan(bp5_mf *mf, int cpt, bp5::TeamPlan &tp, bp5_mf::DevPlan **dpo);
-int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set);
+// window: COMBINE_ALL every shared row; COMBINE_GHOST / COMBINE_OWNED only the rows of ghost / owned DoFs (the boundary-first exchange
+// schedule completes the ghost rows before the interior bricks run); the windows need the run-length form of the pass
+enum { COMBINE_ALL = 0, COMBINE_GHOST = 1, COMBINE_OWNED = 2 };
+int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window = COMBINE_ALL);
 // [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
 bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1);
 
@@ -200,6 +215,7 @@ inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   ShapeArg<n> sh;
   fill_shape(sh, mf);
   const size_t lds = (size_t)TPB * CPT * L::CS * sizeof(double);
+  snprintf(mf->last_apply_kernel, sizeof(mf->last_apply_kernel), "apply_pencil_kernel<%d,%s,%d,%d,%d,%s,%d>", P, COLL ? "true" : "false", TW, LPC, TPB, PF ? "true" : "false", ABL);
   hipLaunchKernelGGL((apply_pencil_kernel<P, COLL, TW, LPC, TPB, PF, ABL>), dim3(a.teams_per_xcd * 8), dim3(64 * TW * TPB), lds, mf->stream, a,
                      sh);
   KERNEL_CHECK();
@@ -281,10 +297,15 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
   const dim3 grid(n_wg), block(256);
-  if constexpr ((ABL & 1048576) != 0) { // fused CG dot products: whole range, overwrite mode, every DoF touched
-    if (!set || atomic_shared || sub_range || mf->defer_combine || !mf->fuse.on) return fail(BP5_ERR_INVALID, "fused dot products need one whole-range overwrite launch");
-    if (n_wg > (uint32_t)PARTIAL_STRIDE / 2) return fail(BP5_ERR_UNSUPPORTED, "too many workgroups for the partial-sum rows");
-    mf->fuse.n_cols = n_wg;
+  snprintf(mf->last_apply_kernel, sizeof(mf->last_apply_kernel), "apply_block_kernel<%d,%s,%d,%d,%d>", P, COLL ? "true" : "false", LPC,
+           atomic_shared ? (set ? SC_OWNER_SET_ATOMIC : SC_OWNER_ADD_ATOMIC) : (set ? SC_OWNER_SET : SC_OWNER_ADD), ABL);
+  if constexpr ((ABL & 1048576) != 0) { // fused CG dot products: overwrite mode, every DoF touched; the whole range in one launch, or
+    // (boundary-first exchange schedule) in block ranges that together cover it, with ONE deferred combine pass
+    if (!set || atomic_shared || (sub_range && !mf->defer_combine) || (mf->defer_combine && !mf->cg_split) || !mf->fuse.on)
+      return fail(BP5_ERR_INVALID, "fused dot products need overwrite launches that cover the whole range");
+    if (mf->fuse.n_cols + n_wg > (uint32_t)PARTIAL_STRIDE / 2) return fail(BP5_ERR_UNSUPPORTED, "too many workgroups for the partial-sum rows");
+    bp.dot_col0 = mf->fuse.n_cols;
+    mf->fuse.n_cols += n_wg;
   }
   if constexpr ((ABL & 1048576) == 0) if (atomic_shared) {
     // brick-surface DoFs by atomics: zero exactly those first (SET mode), no partial slab / combine
@@ -352,6 +373,7 @@ inline int launch_team_t(bp5_mf *mf, const double *coef, const double *src, doub
   const size_t lds = (size_t)CPT * L::CS * sizeof(double);
   const dim3 grid(a.teams_per_xcd * 8), block(64 * TW);
   const bool whole = (c0 == 0 && c1 == mf->n_cells);
+  snprintf(mf->last_apply_kernel, sizeof(mf->last_apply_kernel), "apply_team_kernel<%d,%s,%d,%d,%s,", P, COLL ? "true" : "false", TW, LPC, PF ? "true" : "false");
   if (!whole || mf->force_atomic_scatter) {
     if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     hipLaunchKernelGGL((apply_team_kernel<P, COLL, TW, LPC, PF, SC_ATOMIC, OPT>), grid, block, lds, mf->stream, a, tp, sh);
@@ -399,6 +421,7 @@ inline int launch_march_t(bp5_mf *mf, const double *coef, const double *src, dou
   ShapeArg<n> sh;
   fill_shape(sh, mf);
   const size_t lds = (size_t)CPT * L::CS * sizeof(double);
+  snprintf(mf->last_apply_kernel, sizeof(mf->last_apply_kernel), "apply_march_kernel<%d,%s,%d,%d,%s,%d>", P, COLL ? "true" : "false", TW, LPC, PF ? "true" : "false", ABL);
   hipLaunchKernelGGL((apply_march_kernel<P, COLL, TW, LPC, PF, ABL>), dim3(mp.teams_per_xcd * 8), dim3(64 * TW), lds, mf->stream, a, mp, sh);
   KERNEL_CHECK();
   return BP5_OK;

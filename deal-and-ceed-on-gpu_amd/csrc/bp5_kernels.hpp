@@ -1169,7 +1169,8 @@ struct BlockPlan {
   unsigned long long *stamps; // diagnostic builds only: [n_wg][16] cycle sums per phase (never read by kernels)
   // builds with ABL & 1048576 (fused CG dot products, SolverCGFullMerge's update_b, bp5/solver.h:142-311): src == p, dst == v
   const double *cg_r;         // residual vector r
-  double *dot_partials;       // [7][PARTIAL_STRIDE] row k, column = workgroup: p.v, v.v, r.v, r.r (rows 4-6 = rows 2, 1, 3: D == 1)
+  double *dot_partials;       // [7][PARTIAL_STRIDE] row k, column = dot_col0 + workgroup: p.v, v.v, r.v, r.r (rows 4-6 = rows 2, 1, 3: D == 1)
+  uint32_t dot_col0;          // first column of this launch (the boundary-first schedule runs the bricks in two launches)
   uint32_t n_owned;           // dot products run over owned entries only
   const int *cg_state;        // st[ST_DONE] != 0: the solve has stopped, the launch is a no-op (iterate frozen)
 };
@@ -1696,7 +1697,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
   uint32_t b = bp.wg_block[w];
   const uint32_t b1 = bp.wg_block[w + 1];
   if (b >= b1) {
-    if constexpr (DOTS) { if (t < 7) bp.dot_partials[t * PARTIAL_STRIDE + blockIdx.x] = 0.0; } // an idle workgroup still owns a column
+    if constexpr (DOTS) { if (t < 7) bp.dot_partials[t * PARTIAL_STRIDE + bp.dot_col0 + blockIdx.x] = 0.0; } // an idle workgroup still owns a column
     return;
   }
   uint32_t gp = bp.pass_off[b];
@@ -2022,7 +2023,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
     __syncthreads();
     if (t < 7) {
       const int k = t < 4 ? t : (t == 4 ? 2 : t == 5 ? 1 : 3); // D == 1: r.Dv = r.v, v.Dv = v.v, r.Dr = r.r
-      bp.dot_partials[t * PARTIAL_STRIDE + blockIdx.x] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+      bp.dot_partials[t * PARTIAL_STRIDE + bp.dot_col0 + blockIdx.x] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
     }
   }
   if constexpr (ABL & 4096) {
@@ -2398,6 +2399,10 @@ __global__ void __launch_bounds__(256) combine_kernel(const uint32_t *sh_dof, co
 struct CombineRuns {
   const uint32_t *start, *dof0, *soff, *slots, *tile_run; // dof0 bit 31: the run's DoFs are Dirichlet DoFs
   uint32_t n_shared;
+  // window of this launch: tiles [tile0, tile0 + n_tiles) and, inside them, the DoFs dof_lo <= g < dof_hi only.  The boundary-first
+  // schedule of the halo exchange completes the GHOST rows first (they are sent to their owners while the interior bricks run) and
+  // the owned rows after the last brick; every row is written by exactly one of the two launches, in the same summation order
+  uint32_t tile0, dof_lo, dof_hi;
   // DOTS builds (fused CG dot products, see apply_block_kernel): the launch is a fixed grid walking the tiles
   const double *cg_p, *cg_r;
   double *dot_partials;    // [7][PARTIAL_STRIDE]; this launch writes the columns [dot_col0, dot_col0 + gridDim.x)
@@ -2417,6 +2422,7 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
   if constexpr (DOTS) { if (cr.cg_state[0]) return; }
   // one value: sum of its partials in ascending group order; Dirichlet rows of the fused build store p instead; dot products
   auto finish = [&](uint32_t g, bool dirichlet, double s) {
+    if (g < cr.dof_lo || g >= cr.dof_hi) return; // another launch's row
     if constexpr (DOTS) {
       double vi = s;
       if (dirichlet) { // v = p (copy_constrained_values, bp5/step-64.cu:275); p.v correction as in the block kernel
@@ -2431,7 +2437,7 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
     } else if (ADD) dst[g] += s;
     else dst[g] = s;
   };
-  for (uint32_t tile = blockIdx.x; tile < (DOTS ? cr.n_tiles : blockIdx.x + 1); tile += gridDim.x) {
+  for (uint32_t tile = cr.tile0 + blockIdx.x; tile < (DOTS ? cr.tile0 + cr.n_tiles : cr.tile0 + blockIdx.x + 1); tile += gridDim.x) {
     if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
     const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= COMBINE_TILE
     const uint32_t cnt = r_hi - r_lo + 1;

@@ -358,6 +358,7 @@ class SolverControl:
         self.solve_ms = self.apply_ms_avg = self.operator_ms_avg = 0.0
         self.apply_launches = 0
         self.dot_products_fused = False
+        self.exchange_schedule, self.apply_kernel, self.phase_ms = 0, "", [0.0] * 8
 
     def last_step(self):
         return self._last_step
@@ -396,7 +397,7 @@ class _SolverBase:
         x, b = _vals(x), _vals(b)
         diag = _vals(preconditioner.get_vector()) if preconditioner is not None else None
         prm = _lib.CGParams(self.variant, self.control.max_steps, self.control.tolerance, self.check_every,
-                            1 if self.profile else 0)
+                            int(self.profile))   # False / True / 2 (phase stamps)
         res = _lib.CGResult()
         dptr = _ptr(diag, mf.n_owned) if diag is not None else None
         if isinstance(A, PoissonOperator):
@@ -424,6 +425,7 @@ class _SolverBase:
         c.solve_ms, c.apply_ms_avg, c.apply_launches = res.solve_ms, res.apply_ms_avg, res.apply_launches
         c.operator_ms_avg = res.operator_ms_avg
         c.dot_products_fused = bool(res.dot_products_fused)
+        c.exchange_schedule, c.apply_kernel, c.phase_ms = res.exchange_schedule, res.apply_kernel.decode(), list(res.phase_ms)
         _lib.check(status)
         return res
 

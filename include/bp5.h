@@ -299,9 +299,12 @@ int bp5_halo_gather(bp5_mf *mf, double *v);
 int bp5_halo_scatter_add(bp5_mf *mf, double *v);
 int bp5_halo_zero_ghosts(bp5_mf *mf, double *v);
 /* == MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241).  mode 1: on (the reference's setting);
- *    0: off -- the exchange stays on the handle's stream and the cell loop runs unsplit; 2 (default): the library decides -- on for
- *    slabs of >= 1e6 interior cells, off below: the split costs 50-80 us per application (three launches, four cross-stream
- *    dependencies) and hides one DoF plane each way (profiles/r2 README, p_*) */
+ *    0: off -- the exchange stays on the handle's stream and the cell loop runs unsplit; 2 (default): the library decides.
+ *    Solvers on the block kernel (fused dot products) overlap BOUNDARY-FIRST: the bricks that touch ghost DoFs run first, their rows
+ *    travel to the owners on the communication stream while the interior bricks run (two launches; automatic whenever the
+ *    ghost-touching bricks hold at most a third of the cells); the ghost gather of the search direction travels under the vector update.
+ *    bp5_apply_distributed and the atomic kernels use the three-phase split (interior, boundary, interior): automatic from 1e6
+ *    interior cells on -- it costs three launches and four cross-stream dependencies per application (profiles/r2, r3 READMEs) */
 int bp5_mf_set_overlap(bp5_mf *mf, int mode);
 /* distributed vmult == PoissonOperator::vmult on more than one rank (bp5/step-64.cu:263-276 with the cell_loop of :274).
  *    With the overlapped schedule (bp5_mf_set_overlap): ghost gather started; first part of the interior cells [0, n_interior_cells) underneath it; gather finished; the cells
@@ -323,7 +326,8 @@ typedef struct {
   int check_every;   /* host looks at the device-side convergence flag every k iterations
                         (0 = only at the end); the iterate is frozen on device at convergence
                         either way, so the result does not depend on it                         */
-  int profile;       /* 1 = bracket every operator launch with HIP events                       */
+  int profile;       /* 1 = bracket every operator launch with HIP events; 2 = also stamp the phases of every
+                        iteration (bp5_cg_result.phase_ms; diagnostic: the stamps themselves cost a few us) */
 } bp5_cg_params;
 
 typedef struct {
@@ -335,7 +339,22 @@ typedef struct {
   int apply_launches;
   double operator_ms_avg;  /* profile=1: zero-fill + cell kernel + combine pass (one A*x without halo) */
   int dot_products_fused;  /* 1: the solve formed its dot products inside the operator kernels (bp5_mf_set_cg_fusion) */
+  int exchange_schedule;   /* halo exchange of the operator applications: 0 none (one rank), 1 unsplit (gather, all cells, scatter-add),
+                              2 boundary-first (ghost-touching bricks, exchange on the communication stream under the interior bricks),
+                              3 three-phase (atomic kernels / separate dot products: interior, boundary, interior)            */
+  char apply_kernel[96];   /* the operator kernel the solve launched last, as a profiler prints it (e.g.
+                              "apply_block_kernel<4,false,32,1,1337344>"): what rocprofv3 rows belong to this solve               */
+  /* profile=2, BP5_CG_MERGED: average HIP-event time of the phases of one iteration on the handle's stream (ms), BP5_PHASE_* */
+  double phase_ms[8];
 } bp5_cg_result;
+enum { BP5_PHASE_UPDATE = 0,      /* vector update (+ packing / starting the ghost gather of the new search direction)       */
+       BP5_PHASE_GATHER_WAIT = 1, /* stream waits for the ghost values (exposed part of the gather)                          */
+       BP5_PHASE_OPERATOR = 2,    /* cell kernels + combine pass (boundary-first: + ghost-row combine, exchange start)        */
+       BP5_PHASE_EXCHANGE = 3,    /* exposed part of the scatter-add exchange + unpack (unsplit: the whole exchange)          */
+       BP5_PHASE_REDUCE = 4,      /* local reduction of the partial sums                                                      */
+       BP5_PHASE_ALLREDUCE = 5,   /* RCCL all-reduce of the 7 sums                                                            */
+       BP5_PHASE_CONTROL = 6,     /* scalar step (alpha, beta, stopping test)                                                 */
+       BP5_PHASE_ITERATION = 7    /* whole iteration                                                                          */ };
 
 /* == cg.solve(A, x, b, preconditioner) with DiagonalMatrix (bp5/step-64.cu:446-453,488-495).
  *    diag may be NULL (== 1, bp5/step-64.cu:432).  x is overwritten (x0 = 0, bp5/step-64.cu:449).

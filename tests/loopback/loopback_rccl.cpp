@@ -1,20 +1,35 @@
 // TEST INFRASTRUCTURE, never part of libbp5.so: a host-shared-memory stand-in for the nine RCCL calls of the library, linked
 // into libbp5_loopback.so only (csrc/Makefile target `loopback`).  Purpose: run N ranks of the product's multi-rank code
 // (z-slab meshes, pack/unpack kernels, exchange schedules, fused dot-product corrections, per-iteration all-reduce) as N
-// PROCESSES ON ONE GPU, which RCCL refuses ("Duplicate GPU detected").  Semantics kept: stream order (the stream is drained
-// before a transfer touches a buffer and the transfer is complete when the call returns), grouped send/recv (all sends of a
-// group are buffered before its receives wait: no deadlock between neighbours), messages between a pair of ranks matched in
-// order, all-reduce summed in rank order on every rank.  Nothing here is timed or measured.
+// PROCESSES ON ONE GPU, which RCCL refuses ("Duplicate GPU detected").
+//
+// Semantics kept, and -- unlike the first version of this shim -- kept ASYNCHRONOUSLY, the way RCCL behaves:
+//   * every call only ENQUEUES work on the caller's stream and returns; the transfer happens when the stream gets there
+//     (a D2H copy into a pinned staging buffer, a host function that talks to the peer through shared memory, an H2D copy),
+//     so a product bug in the ordering BETWEEN streams -- a missing hipStreamWaitEvent around a *_start / *_finish pair, a send
+//     buffer re-packed while its message has not left, a ghost range read before its receive has landed -- is not hidden by a
+//     blocking call and shows up as a wrong result;
+//   * BP5_LOOPBACK_DELAY_US=<n>: every transfer sleeps n microseconds on its stream before it touches its buffers (the
+//     communication lags behind the compute stream, as over a slow link);
+//   * BP5_LOOPBACK_POISON=0 switches OFF the default poisoning: a receive first fills its destination with NaN (stream-ordered),
+//     so anything that reads the destination before the message has landed computes NaN;
+//   * grouped send/recv (all sends of a group are buffered before its receives wait: no deadlock between neighbours), messages
+//     between a pair of ranks matched in order, all-reduce summed in rank order on every rank (the same bits everywhere).
+// A failure inside a host function (timeout waiting for a peer, message size mismatch) latches an error: the destination is
+// filled with NaN and every later call of the shim returns ncclSystemError.  Nothing here is timed or measured.
 #include "loopback_rename.h"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <limits>
 #include <random>
 #include <sys/mman.h>
 #include <thread>
@@ -22,7 +37,7 @@
 #include <vector>
 
 namespace {
-constexpr int MAX_RANKS = 4, SLOTS = 4, MAX_REDUCE = 1024;
+constexpr int MAX_RANKS = 4, SLOTS = 4, MAX_REDUCE = 1024, RING = 16;
 constexpr size_t SLOT_BYTES = size_t(4) << 20;
 constexpr double TIMEOUT_S = 120.0;
 
@@ -50,6 +65,38 @@ struct Op {
 };
 thread_local int group_depth = 0;
 thread_local std::vector<Op> queued;
+std::atomic<int> g_error{0}; // latched by host functions
+
+int delay_us()
+{
+  static const int d = [] { const char *e = getenv("BP5_LOOPBACK_DELAY_US"); return e ? atoi(e) : 0; }();
+  return d;
+}
+bool poison()
+{
+  static const bool p = [] { const char *e = getenv("BP5_LOOPBACK_POISON"); return !(e && e[0] == '0'); }();
+  return p;
+}
+
+// pinned staging buffers: a ring; a slot is reused only after the stream work that last touched it has completed
+struct Staging {
+  void *host = nullptr;
+  hipEvent_t done = nullptr;
+  bool used = false;
+};
+Staging g_ring[RING];
+unsigned g_next = 0;
+Staging *acquire()
+{
+  Staging &s = g_ring[g_next++ % RING];
+  if (!s.host) {
+    if (hipHostMalloc(&s.host, SLOT_BYTES) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  if (s.used && hipEventSynchronize(s.done) != hipSuccess) return nullptr; // back-pressure: the host runs at most RING transfers ahead
+  s.used = true;
+  return &s;
+}
 
 template <class F> bool wait_for(F ready)
 {
@@ -71,27 +118,90 @@ bool barrier(Comm *c)
   }
   return wait_for([&] { return r->generation.load() != gen; });
 }
-ncclResult_t run(const Op &op)
+void fill_nan(void *host, size_t bytes)
 {
-  if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
-  if (op.bytes > SLOT_BYTES) return ncclInvalidArgument;
-  Mailbox &m = op.send ? op.c->reg->box[op.c->rank][op.peer] : op.c->reg->box[op.peer][op.c->rank];
-  if (op.send) {
-    if (!wait_for([&] { return m.written.load() - m.consumed.load() < SLOTS; })) return ncclSystemError;
+  double *d = static_cast<double *>(host);
+  for (size_t i = 0; i < bytes / sizeof(double); ++i) d[i] = std::numeric_limits<double>::quiet_NaN();
+}
+
+// ---- host functions (run by the HIP runtime when the stream reaches them; no HIP calls inside)
+struct Xfer {
+  Comm *c;
+  int peer;
+  void *host;
+  size_t bytes;
+};
+void host_sleep(void *) { std::this_thread::sleep_for(std::chrono::microseconds(delay_us())); }
+void host_publish(void *p) // the staged message -> the mailbox to `peer`
+{
+  Xfer *x = static_cast<Xfer *>(p);
+  Mailbox &m = x->c->reg->box[x->c->rank][x->peer];
+  if (!wait_for([&] { return m.written.load() - m.consumed.load() < SLOTS; })) g_error.store(1);
+  else {
     const uint64_t k = m.written.load() % SLOTS;
-    if (hipMemcpy(m.data[k], op.dev, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-    m.bytes[k] = op.bytes;
+    std::memcpy(m.data[k], x->host, x->bytes);
+    m.bytes[k] = x->bytes;
     m.written.fetch_add(1, std::memory_order_release);
+  }
+  delete x;
+}
+void host_consume(void *p) // the next message from `peer` -> the staging buffer
+{
+  Xfer *x = static_cast<Xfer *>(p);
+  Mailbox &m = x->c->reg->box[x->peer][x->c->rank];
+  if (!wait_for([&] { return m.written.load(std::memory_order_acquire) > m.consumed.load(); })) {
+    g_error.store(1);
+    fill_nan(x->host, x->bytes);
   } else {
-    if (!wait_for([&] { return m.written.load(std::memory_order_acquire) > m.consumed.load(); })) return ncclSystemError;
     const uint64_t k = m.consumed.load() % SLOTS;
-    if (m.bytes[k] != op.bytes) {
-      std::fprintf(stderr, "loopback: rank %d expected %zu bytes from rank %d, message has %zu\n", op.c->rank, op.bytes, op.peer, m.bytes[k]);
-      return ncclInvalidArgument;
-    }
-    if (hipMemcpy(op.dev, m.data[k], op.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    if (m.bytes[k] != x->bytes) {
+      std::fprintf(stderr, "loopback: rank %d expected %zu bytes from rank %d, message has %zu\n", x->c->rank, x->bytes, x->peer, m.bytes[k]);
+      g_error.store(2);
+      fill_nan(x->host, x->bytes);
+    } else
+      std::memcpy(x->host, m.data[k], x->bytes);
     m.consumed.fetch_add(1, std::memory_order_release);
   }
+  delete x;
+}
+void host_reduce(void *p) // staged contribution -> sum over the ranks, in rank order, back into the staging buffer
+{
+  Xfer *x = static_cast<Xfer *>(p);
+  Comm *c = x->c;
+  const size_t count = x->bytes / sizeof(double);
+  double *mine = static_cast<double *>(x->host);
+  std::memcpy(c->reg->reduce[c->rank], mine, x->bytes);
+  bool ok = barrier(c);
+  if (ok) {
+    for (size_t i = 0; i < count; ++i) {
+      double a = 0.0;
+      for (int r = 0; r < c->n; ++r) a += c->reg->reduce[r][i]; // rank order: the same bits on every rank
+      mine[i] = a;
+    }
+    ok = barrier(c); // nobody overwrites its slot before everyone has read it
+  }
+  if (!ok) { g_error.store(1); fill_nan(x->host, x->bytes); }
+  delete x;
+}
+
+#define HIPOK(x) do { if ((x) != hipSuccess) return ncclUnhandledCudaError; } while (0)
+ncclResult_t run(const Op &op)
+{
+  if (g_error.load()) return ncclSystemError;
+  if (op.bytes > SLOT_BYTES) return ncclInvalidArgument;
+  Staging *st = acquire();
+  if (!st) return ncclUnhandledCudaError;
+  if (op.send) {
+    if (delay_us() > 0) HIPOK(hipLaunchHostFunc(op.stream, host_sleep, nullptr)); // the message leaves late: its buffer must still be intact
+    HIPOK(hipMemcpyAsync(st->host, op.dev, op.bytes, hipMemcpyDeviceToHost, op.stream));
+    HIPOK(hipLaunchHostFunc(op.stream, host_publish, new Xfer{op.c, op.peer, st->host, op.bytes}));
+  } else {
+    if (poison()) HIPOK(hipMemsetAsync(op.dev, 0xff, op.bytes, op.stream)); // NaN until the message has landed
+    if (delay_us() > 0) HIPOK(hipLaunchHostFunc(op.stream, host_sleep, nullptr));
+    HIPOK(hipLaunchHostFunc(op.stream, host_consume, new Xfer{op.c, op.peer, st->host, op.bytes}));
+    HIPOK(hipMemcpyAsync(op.dev, st->host, op.bytes, hipMemcpyHostToDevice, op.stream));
+  }
+  HIPOK(hipEventRecord(st->done, op.stream));
   return ncclSuccess;
 }
 ncclResult_t flush()
@@ -144,7 +254,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int n, ncclUniqueId id, int rank
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
   Comm *c = reinterpret_cast<Comm *>(comm);
-  if (c) { munmap(c->reg, sizeof(Region)); delete c; }
+  if (c) {
+    hipDeviceSynchronize(); // host functions that still name this communicator have run
+    munmap(c->reg, sizeof(Region));
+    delete c;
+  }
   return ncclSuccess;
 }
 const char *ncclGetErrorString(ncclResult_t r)
@@ -152,8 +266,8 @@ const char *ncclGetErrorString(ncclResult_t r)
   switch (r) {
   case ncclSuccess: return "no error";
   case ncclUnhandledCudaError: return "loopback transport: HIP call failed";
-  case ncclSystemError: return "loopback transport: shared memory failure or timeout waiting for a peer";
-  case ncclInvalidArgument: return "loopback transport: invalid argument or message size mismatch";
+  case ncclSystemError: return "loopback transport: shared memory failure, timeout waiting for a peer or message size mismatch";
+  case ncclInvalidArgument: return "loopback transport: invalid argument";
   default: return "loopback transport: error";
   }
 }
@@ -179,18 +293,14 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
 {
   Comm *c = reinterpret_cast<Comm *>(comm);
   if (!c || t != ncclDouble || op != ncclSum || count > MAX_REDUCE) return ncclInvalidArgument;
-  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-  double mine[MAX_REDUCE], sum[MAX_REDUCE];
-  if (hipMemcpy(mine, send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-  std::memcpy(c->reg->reduce[c->rank], mine, count * sizeof(double));
-  if (!barrier(c)) return ncclSystemError;
-  for (size_t i = 0; i < count; ++i) {
-    double a = 0.0;
-    for (int r = 0; r < c->n; ++r) a += c->reg->reduce[r][i]; // rank order: the same bits on every rank
-    sum[i] = a;
-  }
-  if (!barrier(c)) return ncclSystemError; // nobody overwrites its slot before everyone has read it
-  if (hipMemcpy(recv, sum, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  if (g_error.load()) return ncclSystemError;
+  Staging *st = acquire();
+  if (!st) return ncclUnhandledCudaError;
+  if (delay_us() > 0) HIPOK(hipLaunchHostFunc(s, host_sleep, nullptr));
+  HIPOK(hipMemcpyAsync(st->host, send, count * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPOK(hipLaunchHostFunc(s, host_reduce, new Xfer{c, 0, st->host, count * sizeof(double)}));
+  HIPOK(hipMemcpyAsync(recv, st->host, count * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPOK(hipEventRecord(st->done, s));
   return ncclSuccess;
 }
 }

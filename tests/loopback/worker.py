@@ -54,8 +54,8 @@ def main():
             if mesh.n_ghost:
                 assert float(s_in[no:].abs().max()) == 0.0           # ghosts of src zeroed again
             res[f"A{mode}"] = dst[:no].cpu().numpy()
-        # solvers: plain CG; merged CG unsplit exchange (dot products fused when the block kernel runs), 3-phase overlapped
-        # (separate dot products), library default, fusion switched off
+        # solvers: plain CG; merged CG unsplit exchange (dot products fused when the block kernel runs), overlapped (block kernel:
+        # boundary-first, dot products still fused; atomic kernels: 3-phase, separate dot products), library default, fusion switched off
         norms = []
 
         def solve(Solver, overlap, fusion, key):
@@ -66,6 +66,7 @@ def main():
             Solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
             res["x_" + key] = x[:no].cpu().numpy()
             res["fused_" + key] = np.asarray(bool(ctl.dot_products_fused))
+            res["sched_" + key] = np.asarray(int(ctl.exchange_schedule))
             norms.append(ctl.last_value())
             return x
 
@@ -74,7 +75,9 @@ def main():
         solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped")
         x = solve(pkg.SolverCGFullMerge, 2, True, "merged_default")
         solve(pkg.SolverCGFullMerge, 0, False, "merged_unfused")
-        x2 = solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_again")
+        solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_again")
+        solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped_again")
+        solve(pkg.SolverCG, 1, True, "plain_overlapped")
         res["norms"] = np.asarray(norms)
         # Jacobi-preconditioned merged CG (diagonal assembled across ranks)
         op.mf_data.set_overlap(2)

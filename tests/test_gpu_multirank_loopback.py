@@ -33,9 +33,11 @@ def _free_port():
     return port
 
 
-def _run_ranks(world, args, out, timeout=420, worker=WORKER):
+def _run_ranks(world, args, out, timeout=420, worker=WORKER, delay_us=0):
+    """delay_us: every transfer of the loopback transport lags that long behind its stream (BP5_LOOPBACK_DELAY_US); receives poison their
+    destination with NaN until the message has landed (default of the transport) -- a missing cross-stream wait gives a wrong result"""
     assert os.path.exists(LOOPBACK_LIB), "libbp5_loopback.so missing: run __graft_entry__.build() (make -C .../csrc loopback)"
-    env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", BP5_LOOPBACK_DELAY_US=str(delay_us))
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out] + [str(a) for a in args], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -57,19 +59,22 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("world,p,cells,block,numbering,variant", [
-    (2, 4, (8, 8, 12), (4, 4, 4), 1, 56),  # the bench's configuration: parity-class bricks, block kernel, fused dot products
-    (3, 4, (8, 4, 13), (4, 4, 2), 1, 56),  # first / middle / last rank, ragged slabs (13 layers over 3 ranks), thin bricks
-    (2, 4, (8, 8, 12), (4, 4, 4), 1, 0),   # the library's own choice at this size (too few bricks for the persistent grid: pencil kernel)
-    (3, 2, (3, 3, 7), (0, 0, 0), 0, 0),    # lexicographic cells, atomic pencil kernel
-    (2, 6, (4, 4, 5), (4, 4, 2), 1, 56),   # another degree on the block kernel
-    (4, 4, (4, 4, 9), (4, 4, 2), 1, 56),   # four ranks: two middle ranks, slabs of 3 / 2 / 2 / 2 layers (thinner than a brick)
-    (3, 3, (5, 4, 7), (2, 2, 2), 1, 10),   # team kernel (LDS-staged atomics) behind the exchange
-    (2, 1, (6, 5, 6), (0, 0, 0), 0, 0),    # p = 1
+@pytest.mark.parametrize("world,p,cells,block,numbering,variant,delay_us", [
+    (2, 4, (8, 8, 12), (4, 4, 4), 1, 56, 0),  # the bench's configuration: parity-class bricks, block kernel, fused dot products
+    (2, 4, (8, 8, 12), (4, 4, 4), 1, 56, 400),  # ... with every transfer lagging 0.4 ms behind its stream (cross-stream ordering of both exchange schedules)
+    (3, 4, (8, 4, 13), (4, 4, 2), 1, 56, 0),  # first / middle / last rank, ragged slabs (13 layers over 3 ranks), thin bricks
+    (3, 4, (8, 4, 13), (4, 4, 2), 1, 56, 250),  # ... lagging
+    (2, 4, (8, 8, 12), (4, 4, 4), 1, 0, 0),   # the library's own choice at this size (too few bricks for the persistent grid: pencil kernel)
+    (3, 2, (3, 3, 7), (0, 0, 0), 0, 0, 0),    # lexicographic cells, atomic pencil kernel
+    (3, 2, (3, 3, 7), (0, 0, 0), 0, 0, 250),  # ... lagging (3-phase schedule of the atomic kernels)
+    (2, 6, (4, 4, 5), (4, 4, 2), 1, 56, 0),   # another degree on the block kernel
+    (4, 4, (4, 4, 9), (4, 4, 2), 1, 56, 0),   # four ranks: two middle ranks, slabs of 3 / 2 / 2 / 2 layers (thinner than a brick)
+    (3, 3, (5, 4, 7), (2, 2, 2), 1, 10, 0),   # team kernel (LDS-staged atomics) behind the exchange
+    (2, 1, (6, 5, 6), (0, 0, 0), 0, 0, 0),    # p = 1
 ])
-def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells, block, numbering, variant):
+def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells, block, numbering, variant, delay_us):
     iters = 8
-    _run_ranks(world, [p, *cells, *block, numbering, iters, variant], str(tmp_path))
+    _run_ranks(world, [p, *cells, *block, numbering, iters, variant], str(tmp_path), delay_us=delay_us)
     pr = O.Problem(p, cells, O.QUAD_GAUSS, deform_amp=0.03, kappa=O.kappa_step64)
     nd = pr.mesh.n_dofs
     ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
@@ -88,16 +93,22 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
         assert _rel(full[f"A{mode}"], A_ref) < 1e-13, mode
     x_plain, _, res_plain = O.cg_plain(pr.vmult, b_ref, iters)
     x_merged, _, res_merged = O.cg_merged(pr.vmult, b_ref, iters)
-    assert _rel(full["x_plain"], x_plain) < 1e-11
-    merged = ["merged_unsplit", "merged_overlapped", "merged_default", "merged_unfused", "merged_unsplit_again"]
+    assert _rel(full["x_plain"], x_plain) < 1e-11 and _rel(full["x_plain_overlapped"], x_plain) < 1e-11
+    merged = ["merged_unsplit", "merged_overlapped", "merged_default", "merged_unfused", "merged_unsplit_again", "merged_overlapped_again"]
     for k in merged:
         assert _rel(full["x_" + k], x_merged) < 1e-11, k
     on_block_kernel = int(ranks[0]["variant"]) == 56
     assert on_block_kernel == (variant == 56)
     if on_block_kernel:
         assert np.array_equal(full["x_merged_unsplit"], full["x_merged_unsplit_again"])     # fixed summation orders: reproducible
+        assert np.array_equal(full["x_merged_overlapped"], full["x_merged_overlapped_again"])  # ... in the boundary-first schedule too
+        # the two schedules sum the same per-brick dot products over different column layouts: equal to rounding, far inside the CG tolerance
+        assert _rel(full["x_merged_overlapped"], full["x_merged_unsplit"]) < 1e-12
     for z in ranks:
-        assert bool(z["fused_merged_unsplit"]) == on_block_kernel and not bool(z["fused_merged_overlapped"]) and not bool(z["fused_merged_unfused"])
+        # block kernel: the dot products stay fused in BOTH exchange schedules (1 unsplit, 2 boundary-first); atomic kernels: 3-phase split
+        assert bool(z["fused_merged_unsplit"]) == on_block_kernel and bool(z["fused_merged_overlapped"]) == on_block_kernel and not bool(z["fused_merged_unfused"])
+        assert int(z["sched_merged_unsplit"]) == 1 and int(z["sched_merged_overlapped"]) == (2 if on_block_kernel else 3)
+        assert int(z["sched_merged_default"]) in (1, 2) if on_block_kernel else True
         assert np.array_equal(z["norms"], ranks[0]["norms"])             # every rank sees the same all-reduced residual
     assert abs(ranks[0]["norms"][0] - res_plain) < 1e-9 * np.linalg.norm(b_ref)
     assert abs(ranks[0]["norms"][1] - res_merged) < 1e-9 * np.linalg.norm(b_ref)
@@ -127,8 +138,18 @@ def test_bench_with_two_ranks_as_the_driver_launches_it():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "strong" and "rehearsal" in out
     assert out["config"]["dofs_per_gpu"] < 65 ** 3 and "274625 DoFs" in out["config"]["workload"]      # ONE 16^3-cell problem split over the ranks
-    assert out["config"]["apply_variant"] == 56 and out["config"]["cg_dot_products_fused"] is True      # unsplit exchange, fused dot products
-    assert out["value"] > 0 and "cpu_baseline" not in out
+    assert out["config"]["apply_variant"] == 56 and out["config"]["cg_dot_products_fused"] is True      # fused dot products on both ranks
+    assert out["config"]["cg_dot_products_fused_on_every_rank"] is True and out["config"]["exchange_schedule"] in ("unsplit", "boundary-first")
+    assert out["value"] > 0 and "cpu_baseline" not in out and out["host_setup_s"] > 0
+    assert out["roofline"]["kernel"].startswith("apply_block_kernel<4,false,32,1,")                     # the name the solve itself reports
+    # the N > 1 diagnostics: both exchange schedules timed, every phase of an iteration stamped (max / min over the ranks)
+    ab = out["exchange_ab"]
+    for name, sched in (("unsplit", "unsplit"), ("boundary_first", "boundary-first")):
+        e = ab[name]
+        assert e["schedule_rank0"] == sched and e["dot_products_fused_rank0"] is True and e["ms_per_iteration"] > 0
+        for k in ("update", "gather_wait", "operator", "exchange", "reduce_local", "allreduce", "control", "iteration"):
+            assert e["phases_ms_max_over_ranks"][k] >= e["phases_ms_min_over_ranks"][k] >= 0.0
+        assert e["phases_ms_max_over_ranks"]["operator"] > 0 and e["phases_ms_max_over_ranks"]["iteration"] > 0
 
 
 @pytest.mark.parametrize("world,p,amp", [(2, 2, 0.03), (3, 3, 0.0), (2, 4, 0.02)])

@@ -1218,8 +1218,8 @@ def test_block_kernel_behind_the_halo_exchange(variant, neighbours):
     want_acc[c] = src[c]
     assert float((d_acc - want_acc).abs().max()) < 1e-12 * float(want_acc.abs().max())
     b = op.assemble_rhs()
-    xs = []
-    for overlap in (1, 0):
+    xs, scheds = [], []
+    for overlap in (1, 0, 1):
         assert L.bp5_mf_set_overlap(h, overlap) == 0
         x = op.initialize_dof_vector()
         ctl = pkg.IterationNumberControl(10, 0.0)
@@ -1228,10 +1228,15 @@ def test_block_kernel_behind_the_halo_exchange(variant, neighbours):
         assert L.bp5_apply_distributed(h, ptr(op.coef), ptr(xin), ptr(Ax), 1) == 0
         assert abs(float(torch.linalg.norm((Ax - b)[:no])) - ctl.last_value()) < 1e-9 * ctl.initial_value()
         xs.append(x)
+        scheds.append((ctl.exchange_schedule, ctl.dot_products_fused))
     if variant == 56:
-        # overlap on: separate dot-product kernel; overlap off (unsplit exchange): the dot products are formed inside the block
-        # kernel on every rank's cells and the owners' unpack kernel corrects v.v and r.v for the contributions it adds
-        assert float((xs[0] - xs[1]).abs().max()) < 1e-11 * float(xs[1].abs().max())
+        # the dot products are formed inside the block kernel on every rank's cells in BOTH exchange schedules (the owners' unpack kernel
+        # corrects v.v and r.v for the contributions it adds): overlap on = boundary-first (ghost-touching bricks, their combine rows, the
+        # exchange on the communication stream under the interior bricks), overlap off = one launch, exchange on the compute stream
+        assert scheds == [(2, True), (1, True), (2, True)]
+        assert ctl.apply_kernel.startswith("apply_block_kernel<4,false,32,1,") and int(ctl.apply_kernel.split(",")[-1].rstrip(">")) & 1048576
+        assert torch.equal(xs[0], xs[2])                  # fixed summation order: the boundary-first schedule is bitwise reproducible
+        assert float((xs[0] - xs[1]).abs().max()) < 1e-12 * float(xs[1].abs().max())  # (same per-brick sums, different column layout of the dot products)
         assert L.bp5_mf_set_overlap(h, 0) == 0
         sols = []
         for fused in (True, False, True):
@@ -1243,8 +1248,21 @@ def test_block_kernel_behind_the_halo_exchange(variant, neighbours):
             sols.append(x)
         assert torch.equal(sols[0], sols[2])              # fixed summation order: bitwise reproducible
         assert torch.equal(sols[0], xs[1])                # (the unsplit solve above took the fused path too)
-        assert torch.equal(sols[1], xs[0])                # separate dot products: bitwise independent of the exchange schedule
         assert float((sols[0] - sols[1]).abs().max()) < 1e-11 * float(sols[1].abs().max())
+        # separate dot products: bitwise independent of the exchange schedule (3-phase with combine windows against unsplit)
+        assert L.bp5_mf_set_overlap(h, 1) == 0
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(10, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert not ctl.dot_products_fused and ctl.exchange_schedule == 3 and torch.equal(x, sols[1])
+        op.mf_data.set_cg_fusion(True)
+        # phase stamps (profile = 2): every phase of the boundary-first iteration is stamped; the stamps do not change the result
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(10, 0.0)
+        pkg.SolverCGFullMerge(ctl, profile=2).solve(op, x, b, pkg.DiagonalMatrix())
+        assert torch.equal(x, xs[0]) and ctl.exchange_schedule == 2
+        ph = ctl.phase_ms
+        assert all(v >= 0.0 for v in ph) and ph[0] > 0 and ph[2] > 0 and abs(sum(ph[:7]) - ph[7]) < 0.25 * ph[7] + 0.05
     else:
         assert float((xs[0] - xs[1]).abs().max()) < 1e-11 * float(xs[1].abs().max())
     op.mf_data.synchronize()
