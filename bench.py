@@ -131,7 +131,7 @@ def self_launch(n):
 
 
 PHASES = ["update", "gather_wait", "operator", "exchange", "reduce_local", "allreduce", "control", "iteration"]   # bp5.h BP5_PHASE_*
-SCHEDULES = {0: "none (one rank)", 1: "unsplit", 2: "boundary-first", 3: "three-phase"}                          # bp5_cg_result.exchange_schedule
+SCHEDULES = {0: "none (one rank)", 1: "unsplit", 2: "boundary-first", 3: "three-phase", 4: "under-combine"}       # bp5_cg_result.exchange_schedule
 CONFIG_SIZES = {1: 367, 2: 184, 3: 122, 4: 92, 5: 73, 6: 61, 7: 52, 8: 46}    # BASELINE config 4: ~5e7 DoFs per degree
 
 
@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--variant", choices=["merged", "plain"], default="merged")
     ap.add_argument("--apply-variant", type=int, default=0)
     ap.add_argument("--overlap", type=int, choices=[0, 1, 2], default=2,
-                    help="N > 1: halo-exchange schedule of the timed solve (bp5_mf_set_overlap): 0 unsplit, 1 boundary-first, 2 the library decides")
+                    help="N > 1: halo-exchange schedule of the timed solve (bp5_mf_set_overlap): 0 unsplit, 1 boundary-first, 2 the library decides (exchange under the owned-row combine)")
     ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6",
                     help="merged6: the reference's six stored planes per q-point (G=6, default); affine: per-cell metric + one scalar plane (G=1), affine meshes only")
     ap.add_argument("--cell-block", type=int, nargs=3, default=None,
@@ -347,7 +347,7 @@ def main():
     if world > 1 and not args.no_exchange_ab and args.variant == "merged":
         exchange_ab = {}
         k_ab = max(10, min(args.steps, 40))
-        for mode, name in ((0, "unsplit"), (1, "boundary_first")):
+        for mode, name in ((0, "unsplit"), (1, "boundary_first"), (2, "automatic")):
             try:
                 op.mf_data.set_overlap(mode)
                 timed_solve(3)
@@ -363,8 +363,10 @@ def main():
             except Exception as e:   # noqa: BLE001
                 die(f"exchange A/B leg '{name}' (bp5_mf_set_overlap({mode}))", e)
         op.mf_data.set_overlap(args.overlap)
-        exchange_ab["note"] = ("same problem, same kernels; unsplit = gather, one launch, scatter-add on the compute stream; boundary_first = "
-                               "ghost-touching bricks first, scatter-add on the communication stream under the interior bricks.  phases: HIP "
+        exchange_ab["note"] = ("same problem, same kernels, same bits; unsplit = gather, one launch, combine, scatter-add on the compute stream; "
+                               "boundary_first = ghost-touching bricks first inside the launch, ghost rows + scatter-add on the communication stream "
+                               "under the interior bricks; automatic = the library's default: one launch, ghost rows combined first, scatter-add on "
+                               "the communication stream under the owned-row combine.  phases: HIP "
                                "events on the solver's stream (exchange = exposed part incl. unpack; gather_wait = exposed part of the ghost "
                                "gather that travels under the vector update)")
 

@@ -169,7 +169,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   hipStreamSynchronize(mf->stream);
   void *ptrs[] = {mf->d_constrained_bits, mf->d_l2g, mf->d_constrained, mf->d_send_idx, mf->d_coords, mf->d_tab, mf->d_tab_gauss, mf->d_l2g_padded,
                   mf->d_constraint_mask, mf->d_inv_jac, mf->d_JxW, mf->d_qpoints, mf->d_sendbuf, mf->d_recvbuf, mf->d_partials,
-                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell, mf->d_hang_mask, mf->d_hang_I, mf->d_send_dirichlet};
+                  mf->d_sc, mf->d_scalar, mf->d_st, mf->ws_base, mf->d_stamps, mf->d_evec, mf->d_scalar_plane, mf->d_gcell, mf->d_hang_mask, mf->d_hang_I, mf->d_send_dirichlet, mf->d_signal};
   for (void *p : ptrs) if (p) hipFree(p);
   if (mf->h_sc) hipHostFree(mf->h_sc);
   if (mf->h_st) hipHostFree(mf->h_st);
@@ -948,6 +948,20 @@ static int halo_streams(bp5_mf *mf)
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   HIP_TRY(hipStreamCreateWithPriority(&mf->comm_stream, hipStreamNonBlocking, prio_hi));
   for (hipEvent_t &e : mf->ev_halo) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  // boundary-first schedule inside ONE launch: the communication stream waits for a counter the block kernel's workgroups bump once
+  // their ghost-touching bricks are written out (hipStreamWaitValue64: a barrier-value packet, no kernel, ~1 us wake-up: profiles/r3).
+  // Without it (or with BP5_BOUNDARY_FIRST=launches, the A/B knob) the ghost-touching bricks get a launch of their own.
+  int can = 0;
+  if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, mf->device) != hipSuccess) can = 0;
+  const char *e = getenv("BP5_BOUNDARY_FIRST");
+  if (e && !strcmp(e, "launches")) can = 0;
+  mf->can_wait_value = can;
+  if (can && !mf->d_signal) {
+    HIP_TRY(hipMalloc((void **)&mf->d_signal, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(mf->d_signal, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    mf->signal_target = 0;
+  }
   return BP5_OK;
 }
 extern "C" int bp5_mf_set_overlap(bp5_mf *mf, int mode)
@@ -1009,11 +1023,11 @@ extern "C" int bp5_halo_gather(bp5_mf *mf, double *v)
   return bp5_halo_gather_finish(mf, v);
 }
 // compress(add): ghost contributions travel back to the owners and are added; ghosts zeroed
-static int scatter_exchange(bp5_mf *mf, double *v, bool on_comm_stream)
+static int scatter_exchange(bp5_mf *mf, double *v, bool on_comm_stream, bool ordered_by_caller = false)
 {
   mf->overlap_now = on_comm_stream;
   hipStream_t cs = mf->overlap_now ? mf->comm_stream : mf->stream;
-  if (mf->overlap_now) { // the ghost entries are complete at this point of the compute stream
+  if (mf->overlap_now && !ordered_by_caller) { // the ghost entries are complete at this point of the compute stream
     HIP_TRY(hipEventRecord(mf->ev_halo[2], mf->stream));
     HIP_TRY(hipStreamWaitEvent(cs, mf->ev_halo[2], 0));
   }
@@ -1272,7 +1286,25 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
     mf->fuse.on = true; mf->fuse.p = src; mf->fuse.r = fuse_r; mf->fuse.n_cols = 0;
     int st = BP5_OK;
     bool marked = false;
-    if (!split) {
+    if (!split && mf->cg_late) {
+      // all bricks in one launch; then the GHOST rows of the combine pass (a small launch), the exchange on the communication stream,
+      // and the owned rows combined underneath it: nothing runs beside the bandwidth-bound brick kernel (a co-running RCCL kernel
+      // crawls there -- 300 us for one DoF plane -- and slows it: profiles/r3), the exchange hides behind the owned-row combine
+      bp5_mf::DevPlan *dp = nullptr;
+      st = get_plan_raw(mf, -block_cpt(mf), &dp);
+      if (st == BP5_OK) st = halo_streams(mf);
+      mf->defer_combine = true;
+      if (st == BP5_OK) st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
+      mf->defer_combine = false;
+      if (st == BP5_OK) st = prof.mark(2);
+      if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+      if (st == BP5_OK) st = scatter_exchange(mf, dst, true);
+      if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, mf->n_ghost ? COMBINE_OWNED : COMBINE_ALL);
+      if (st == BP5_OK) st = prof.mark(3);
+      if (prof.on) prof.used += 4;
+      if (st == BP5_OK) st = phase_mark(mf, 3);
+      if (st == BP5_OK) st = bp5_halo_scatter_add_finish(mf, dst);
+    } else if (!split) {
       if (prof.on) mf->prof_mark = mf->ev_pool[prof.used + 2];
       st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
       marked = prof.on && mf->prof_mark == nullptr;
@@ -1285,19 +1317,43 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
     } else {
       bp5_mf::DevPlan *dp = nullptr;
       st = get_plan_raw(mf, -block_cpt(mf), &dp);
+      if (st == BP5_OK) st = halo_streams(mf);
       const int user_variant = mf->apply_variant;
       mf->apply_variant = 56;    // every range takes the block kernel, however few bricks it holds
       mf->defer_combine = true;  // one combine pass per window, launched here
-      if (st == BP5_OK && mf->n_interior < mf->n_cells) {
-        st = launch_apply(mf, coef, src, dst, mf->n_interior, mf->n_cells, true); // bricks that touch ghosts
-        if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+      const bool has_boundary = mf->n_interior < mf->n_cells, in_one_launch = mf->can_wait_value == 1 && has_boundary && mf->n_interior > 0 && mf->blk_two_parts;
+      if (st == BP5_OK && in_one_launch) {
+        // ONE launch: every workgroup walks its share of the ghost-touching bricks first and counts itself in; the communication
+        // stream waits for the count, combines the ghost rows and sends them while the same launch works through the interior bricks
+        mf->blk_signal = true;
+        st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
+        mf->blk_signal = false;
+        if (st == BP5_OK && hipStreamWaitValue64(mf->comm_stream, mf->d_signal, mf->signal_target, hipStreamWaitValueGte, ~0ull) != hipSuccess)
+          st = fail(BP5_ERR_HIP, "hipStreamWaitValue64");
+        if (st == BP5_OK && mf->n_ghost) {
+          hipStream_t compute = mf->stream;
+          mf->stream = mf->comm_stream; // the ghost-row combine runs on the communication stream, between the wait and the send
+          st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+          mf->stream = compute;
+        }
+        if (st == BP5_OK) st = scatter_exchange(mf, dst, true, true);
+      } else {
+        if (st == BP5_OK && has_boundary) {
+          const bool two = mf->blk_two_parts;
+          mf->blk_two_parts = false; // (range launches)
+          st = launch_apply(mf, coef, src, dst, mf->n_interior, mf->n_cells, true); // bricks that touch ghosts
+          if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+          if (st == BP5_OK) st = scatter_exchange(mf, dst, true); // send the ghost rows / post the receives: under the interior bricks
+          if (st == BP5_OK && mf->n_interior) st = launch_apply(mf, coef, src, dst, 0, mf->n_interior, true);
+          mf->blk_two_parts = two;
+        } else { // (a rank without ghost-touching cells only receives: post the receives, then all bricks)
+          if (st == BP5_OK) st = scatter_exchange(mf, dst, true);
+          if (st == BP5_OK) st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
+        }
       }
-      if (st == BP5_OK) st = halo_streams(mf);
-      if (st == BP5_OK) st = scatter_exchange(mf, dst, true); // send the ghost rows / post the receives: under the interior bricks
-      if (st == BP5_OK && mf->n_interior) st = launch_apply(mf, coef, src, dst, 0, mf->n_interior, true);
       mf->defer_combine = false;
       mf->apply_variant = user_variant;
-      if (st == BP5_OK) st = prof.mark(2); // (the profile brackets both brick launches + the ghost-row combine)
+      if (st == BP5_OK) st = prof.mark(2); // (the profile brackets the brick launch(es))
       if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, mf->n_ghost ? COMBINE_OWNED : COMBINE_ALL);
       if (st == BP5_OK) st = prof.mark(3);
       if (prof.on) prof.used += 4;
@@ -1416,11 +1472,12 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   int status = BP5_OK;
   // fused dot products: whenever the operator resolves to the packed block kernel on all cells of one rank (merged solver: and D == 1;
   // the plain solver takes only d.h = the quadrature-point energy from the kernel, which no preconditioner enters).
-  // Across ranks the fused iteration keeps its dot products in BOTH exchange schedules: unsplit (gather, one launch, scatter-add on the
-  // compute stream) or boundary-first (bp5_mf_set_overlap 1, or 2 = automatic when the ghost-touching bricks are a minority: they run
-  // first, their rows travel to the owners on the communication stream under the interior bricks; solver_vmult).
+  // Across ranks the fused iteration keeps its dot products in every exchange schedule (solver_vmult): unsplit (bp5_mf_set_overlap 0:
+  // gather, one launch, combine, scatter-add on the compute stream), boundary-first (1, the reference's setting: the ghost-touching
+  // bricks come first, their rows travel to the owners on the communication stream under the interior bricks), and the automatic
+  // choice (2): one launch, ghost rows combined first, the exchange under the owned-row combine.
   const bool dist_solve = mf->comm && !mf->neighbors.empty();
-  bool split = false;
+  bool split = false, split_possible = false, late = false;
   if (!user && mf->cg_fusion && (plain || !diag) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
       effective_variant(mf, 0, mf->n_cells) == 56) {
     bp5_mf::DevPlan *dp = nullptr;
@@ -1429,17 +1486,23 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     if (fused_dots && dist_solve) {
       uint32_t b0_, b1_;
       const bool possible = !mf->h_block_off.empty() && (mf->n_interior == 0 || mf->n_interior == mf->n_cells || block_aligned(mf, 0, mf->n_interior, &b0_, &b1_));
-      const bool pays = (uint64_t)mf->n_interior >= 2ull * (mf->n_cells - mf->n_interior); // ghost-touching bricks: at most a third of the cells
-      split = possible && (mf->overlap == 1 || (mf->overlap == 2 && pays));
+      split_possible = possible;
+      split = possible && mf->overlap == 1;
       if (mf->overlap == 1 && !split) fused_dots = false; // explicit overlap on a mesh that cannot run boundary-first: 3-phase schedule, separate dot products
+      // automatic: one launch, ghost rows combined first, exchange under the owned-row combine (needs the run-length combine windows)
+      late = fused_dots && mf->overlap == 2 && (dp->n_shared == 0 || (dp->cr_tile && !mf->combine_csr));
     }
   }
   struct OverlapGuard { // the fused exchanges choose their streams themselves (solver_vmult), whatever the slab size
     bp5_mf *m; int saved;
-    ~OverlapGuard() { m->overlap = saved; m->cg_split = false; }
+    ~OverlapGuard() { m->overlap = saved; m->cg_split = false; m->cg_late = false; m->blk_two_parts = false; m->blk_signal = false; }
   } overlap_guard{mf, mf->overlap};
   if (fused_dots && dist_solve) mf->overlap = 0;
   mf->cg_split = split;
+  mf->cg_late = late;
+  // whole-range launches of a distributed fused solve walk the ghost-touching bricks first in EITHER exchange schedule: same workgroup
+  // ranges, same dot-product columns -- the two schedules then differ only in where the exchange is enqueued and give the same bits
+  mf->blk_two_parts = fused_dots && dist_solve && split_possible;
   // one rank, separate dot-product kernel: the two small launches around an operator that scatters with atomics fold into their
   // neighbours -- the update kernel stores the zeros the operator needs in h / v (it holds the values in registers for the last time),
   // the dot-product kernel applies the Dirichlet copy while it reads both vectors (bitmap of the Dirichlet DoFs)
@@ -1582,7 +1645,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   res->apply_ms_avg = res->operator_ms_avg = 0.0;
   res->apply_launches = prof.used / 4;
   res->dot_products_fused = fused_dots ? 1 : 0;
-  res->exchange_schedule = !dist_solve ? 0 : split ? 2 : fused_dots ? 1 : overlap_wanted(mf) ? 3 : 1;
+  res->exchange_schedule = !dist_solve ? 0 : split ? 2 : late ? 4 : fused_dots ? 1 : overlap_wanted(mf) ? 3 : 1;
   if (prof.on && prof.used) {
     double tot = 0.0, tot_op = 0.0;
     for (int k = 0; k < prof.used; k += 4) {

@@ -88,8 +88,16 @@ struct bp5_mf {
   bool overlap_now = false;   // the decision for the exchange in flight (set by *_start)
   bool cg_fusion = true;      // SolverCGFullMerge: dot products inside the block kernel's write-out when the plan allows
   bool defer_combine = false; // block kernel on cell ranges: partial slab now, ONE combine pass after the last range
-  bool cg_split = false;      // set by a solve with fused dot products across ranks: boundary-first schedule -- the bricks run in two
-                              // launches (ghost-touching ones first), one combine pass per window, the exchange under the interior bricks
+  bool cg_split = false;      // set by a solve with fused dot products across ranks: boundary-first schedule -- the ghost-touching bricks
+                              // run first, one combine pass per window, the exchange travels under the interior bricks
+  // block kernel launches over ALL bricks of a slab with ghosts: two parts per workgroup (its share of the ghost-touching bricks, then
+  // its interior bricks); blk_signal: the launch counts the workgroups whose first part is written out at *d_signal (monotonic:
+  // signal_target = the count after the last launch), so that the communication stream can wait for the ghost rows mid-kernel
+  bool cg_late = false;       // ... or: all bricks in one launch, the ghost rows combined first, the exchange under the owned-row combine
+  bool blk_two_parts = false, blk_signal = false;
+  unsigned long long *d_signal = nullptr;
+  uint64_t signal_target = 0;
+  int can_wait_value = -1;    // hipDeviceAttributeCanUseStreamWaitValue (and not switched off by BP5_BOUNDARY_FIRST=launches)
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
@@ -122,7 +130,7 @@ struct bp5_mf {
     std::vector<double> h_cost;                       // [n_groups+1] prefix sum of the estimated cost of the blocks (pass units)
     // block ranges of the persistent workgroups, one device array per (n_wg, first block, end block) ever launched: the
     // interior / boundary ranges of the overlapped schedule alternate, nothing is freed or re-uploaded inside a solve
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t *> *wg_blocks = nullptr;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t *> *wg_blocks = nullptr; // key: n_wg, first, end, first block of part 0 (0: one part)
     uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     uint32_t n_shared_owned = 0; // shared DoFs are listed in ascending order: ordinals [0, n_shared_owned) are owned DoFs, the rest ghosts
@@ -264,21 +272,45 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   { // block ranges of the persistent workgroups: equal shares of the estimated COST (thin or partial bricks are cheaper per
     // block but dearer per cell than full ones), cached
     const uint32_t B0 = bp.blk_begin, B1 = bp.blk_begin + bp.n_blocks;
-    if (!dp->wg_blocks) dp->wg_blocks = new std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t *>;
-    auto key = std::make_tuple(n_wg, B0, B1);
+    // two parts (whole-range launches on a slab whose ghost-touching bricks come last, [Bs, B1)): every workgroup takes an equal share
+    // of the ghost-touching bricks first, then interior bricks up to an equal share of the TOTAL cost
+    uint32_t Bs = 0, bs0_ = 0;
+    const bool two_parts = mf->blk_two_parts && !sub_range && mf->n_interior > 0 && mf->n_interior < mf->n_cells && block_aligned(mf, 0, mf->n_interior, &bs0_, &Bs) && Bs > B0 && Bs < B1;
+    if (!dp->wg_blocks) dp->wg_blocks = new std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t *>;
+    auto key = std::make_tuple(n_wg, B0, B1, two_parts ? Bs : 0u);
     auto itw = dp->wg_blocks->find(key);
     if (itw == dp->wg_blocks->end()) {
-      std::vector<uint32_t> wb(n_wg + 1);
       const std::vector<double> &pc = dp->h_cost;
-      const double c0 = pc[B0], total = pc[B1] - c0;
-      for (uint32_t w = 0; w <= n_wg; ++w)
-        wb[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + B1 + 1, c0 + total * w / n_wg - 1e-9) - pc.begin());
-      wb[0] = B0; wb[n_wg] = B1;
+      std::vector<uint32_t> wb((two_parts ? 2 : 1) * (size_t)(n_wg + 1));
+      if (!two_parts) {
+        const double c0 = pc[B0], total = pc[B1] - c0;
+        for (uint32_t w = 0; w <= n_wg; ++w)
+          wb[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + B1 + 1, c0 + total * w / n_wg - 1e-9) - pc.begin());
+        wb[0] = B0; wb[n_wg] = B1;
+      } else {
+        uint32_t *wa = wb.data(), *wi = wb.data() + n_wg + 1; // part 0: [Bs, B1), part 1: [B0, Bs)
+        const double ca = pc[Bs], ta = pc[B1] - ca, ci = pc[B0], ti = pc[Bs] - ci;
+        for (uint32_t w = 0; w <= n_wg; ++w) {
+          wa[w] = (uint32_t)(std::lower_bound(pc.begin() + Bs, pc.begin() + B1 + 1, ca + ta * w / n_wg - 1e-9) - pc.begin());
+          if (w == 0) wa[w] = Bs;
+          if (w == n_wg) wa[w] = B1;
+          const double want = (ta + ti) * w / n_wg - (pc[wa[w]] - ca); // interior cost the workgroups before w should hold
+          wi[w] = (uint32_t)(std::lower_bound(pc.begin() + B0, pc.begin() + Bs + 1, ci + std::max(want, 0.0) - 1e-9) - pc.begin());
+          if (w > 0) wi[w] = std::max(wi[w], wi[w - 1]);
+        }
+        wi[0] = B0; wi[n_wg] = Bs;
+      }
       uint32_t *dev = nullptr;
       BP5_TRY(upload(&dev, wb.data(), wb.size()));
       itw = dp->wg_blocks->emplace(key, dev).first;
     }
     bp.wg_block = itw->second;
+    bp.n_parts = two_parts ? 2u : 1u;
+    bp.signal = nullptr;
+    if (mf->blk_signal) {
+      if (!two_parts || !mf->d_signal) return fail(BP5_ERR_INVALID, "boundary-first signal: the launch has no separate ghost-touching part");
+      bp.signal = mf->d_signal;
+    }
   }
   bp.cg_r = mf->fuse.r; bp.dot_partials = mf->d_partials; bp.n_owned = mf->n_owned; bp.cg_state = mf->d_st;
   bp.stamps = nullptr;
@@ -296,12 +328,13 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   fill_shape(sh, mf);
   const bool set = overwrite && dp->covers_all;
   if (overwrite && !set) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+  if (bp.signal && atomic_shared) return fail(BP5_ERR_INVALID, "boundary-first signal: owner-store launches only");
   const dim3 grid(n_wg), block(256);
   snprintf(mf->last_apply_kernel, sizeof(mf->last_apply_kernel), "apply_block_kernel<%d,%s,%d,%d,%d>", P, COLL ? "true" : "false", LPC,
            atomic_shared ? (set ? SC_OWNER_SET_ATOMIC : SC_OWNER_ADD_ATOMIC) : (set ? SC_OWNER_SET : SC_OWNER_ADD), ABL);
   if constexpr ((ABL & 1048576) != 0) { // fused CG dot products: overwrite mode, every DoF touched; the whole range in one launch, or
     // (boundary-first exchange schedule) in block ranges that together cover it, with ONE deferred combine pass
-    if (!set || atomic_shared || (sub_range && !mf->defer_combine) || (mf->defer_combine && !mf->cg_split) || !mf->fuse.on)
+    if (!set || atomic_shared || (sub_range && !mf->defer_combine) || (mf->defer_combine && !mf->cg_split && !mf->cg_late) || !mf->fuse.on)
       return fail(BP5_ERR_INVALID, "fused dot products need overwrite launches that cover the whole range");
     if (mf->fuse.n_cols + n_wg > (uint32_t)PARTIAL_STRIDE / 2) return fail(BP5_ERR_UNSUPPORTED, "too many workgroups for the partial-sum rows");
     bp.dot_col0 = mf->fuse.n_cols;
@@ -335,6 +368,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     hipLaunchKernelGGL(kern, grid, block, lds, mf->stream, a, bp, sh);
   }
   KERNEL_CHECK();
+  if (bp.signal) mf->signal_target += n_wg; // the launch was accepted: every workgroup counts itself in once; the caller waits for this value
   if (ABL & 4096) { // diagnostic build: print the per-phase cycle shares (never quote its run time)
     HIP_TRY(hipStreamSynchronize(mf->stream));
     std::vector<unsigned long long> hs((size_t)n_wg * 16);

@@ -1160,7 +1160,13 @@ struct BlockPlan {
   double *partial;            // [off[n_blocks]]
   uint32_t n_blocks, n_wg;    // blocks of this launch; persistent workgroups, n_wg a multiple of 8
   uint32_t blk_begin;         // first block of this launch (block-aligned cell ranges; 0 for the whole mesh)
-  const uint32_t *wg_block;   // [n_wg+1] first block of every persistent workgroup: ranges balanced by PASSES, not blocks
+  const uint32_t *wg_block;   // [n_parts][n_wg+1] first block of every persistent workgroup: ranges balanced by estimated cost
+  // boundary-first launches (halo exchange under the interior bricks): n_parts == 2 -- every workgroup walks its share of the
+  // ghost-touching bricks (part 0) before its interior bricks (part 1), as ONE sequence of passes (the software pipeline runs across
+  // the seam), and counts itself in at *signal once its part 0 is written out; the communication stream waits for the count
+  // (hipStreamWaitValue64), combines the ghost rows and sends them
+  uint32_t n_parts;           // 1 or 2
+  unsigned long long *signal; // NULL: nobody waits
   // run-length form of dofs (builds with ABL & 16384): run r of block b covers the list slots [runs[2r], runs[2r+2]) and
   // the consecutive DoFs starting at runs[2r+1] (bit 31 as in dofs); at most BLOCK_MAX_RUNS runs per block
   const uint32_t *run_off;    // [n_blocks+1]
@@ -1693,19 +1699,45 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
   constexpr bool DOTS = (ABL & 1048576) != 0;
   static_assert(!DOTS || (((ABL & 16384) != 0) && ((ABL & 8192) != 0) && SCATTER == SC_OWNER_SET), "fused dot products: run-length write-out, sequential tiles, overwrite mode");
   double ds[4] = {0.0, 0.0, 0.0, 0.0};
-  if constexpr (DOTS) { if (bp.cg_state[0]) return; }
-  uint32_t b = bp.wg_block[w];
-  const uint32_t b1 = bp.wg_block[w + 1];
-  if (b >= b1) {
+  // this workgroup is through with its ghost-touching bricks: release its stores (every wave's -- the barrier orders them before
+  // thread 0's device-scope fence) and count it in
+  auto signal_part_done = [&](bool stores_pending) {
+    if (stores_pending) { lds_drain(); __syncthreads(); }
+    if (t == 0) {
+      // release only (L2 write-back, no invalidate: the brick-local re-reads of src keep their L2 lines); whoever consumes the rows is a
+      // later kernel launch on the communication stream, which acquires at its start
+      if (stores_pending) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(bp.signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if constexpr (DOTS) {
+    if (bp.cg_state[0]) { // the solve has stopped: a no-op launch -- whoever waits for the ghost rows must still be released
+      if (bp.signal) signal_part_done(false);
+      return;
+    }
+  }
+  // The workgroup's blocks: [ba0, ba1) (part 0) then [bb0, bb1) (part 1; empty in one-part launches), walked as ONE sequence of
+  // virtual block indices vb = 0 .. nb - 1 and virtual pass indices gp = 0 .. gp_end - 1; only the look-ups translate (scalar
+  // arithmetic: everything here is wave-uniform)
+  const uint32_t ba0 = bp.wg_block[w], ba1 = bp.wg_block[w + 1];
+  const uint32_t bb0 = bp.n_parts > 1 ? bp.wg_block[bp.n_wg + 1 + w] : 0u, bb1 = bp.n_parts > 1 ? bp.wg_block[bp.n_wg + 1 + w + 1] : 0u;
+  const uint32_t nba = ba1 - ba0, b1 = nba + (bb1 - bb0);          // blocks of part 0 / of both parts
+  if (b1 == 0) {
     if constexpr (DOTS) { if (t < 7) bp.dot_partials[t * PARTIAL_STRIDE + bp.dot_col0 + blockIdx.x] = 0.0; } // an idle workgroup still owns a column
+    if (bp.signal) signal_part_done(false);
     return;
   }
-  uint32_t gp = bp.pass_off[b];
-  const uint32_t gp_end = bp.pass_off[b1];
-  uint32_t boundary = bp.pass_off[b + 1];
-  uint32_t o0 = bp.off[b];
-  int m = (int)(bp.off[b + 1] - o0);
-  int n_rounds = bp.blk_rounds[b];
+  if (bp.signal && nba == 0) signal_part_done(false);               // no ghost-touching brick in this workgroup's share
+  const uint32_t pa0 = bp.pass_off[ba0], npa = bp.pass_off[ba1] - pa0, pb0 = bp.pass_off[bb0]; // physical first passes, passes of part 0
+  auto blk = [&](uint32_t vb) -> uint32_t { return vb < nba ? ba0 + vb : bb0 + (vb - nba); };      // physical block of a virtual one
+  uint32_t b = 0;                                                   // virtual block index
+  uint32_t pb = blk(0);                                             // ... and its physical id
+  uint32_t gp = 0;
+  const uint32_t gp_end = npa + (bp.pass_off[bb1] - pb0);
+  uint32_t boundary = bp.pass_off[pb + 1] - bp.pass_off[pb];        // virtual pass index behind the current block
+  uint32_t o0 = bp.off[pb];
+  int m = (int)(bp.off[pb + 1] - o0);
+  int n_rounds = bp.blk_rounds[pb];
   // write-out by runs: the block's run table is fetched into registers at the top of its last pass, parked in one of
   // two LDS tables (block parity: a wave may still be writing out block b while another one enters b + 1) right
   // before the write-out barrier, and every thread walks it forward for its slots -- no list loads in the write-out
@@ -1713,8 +1745,8 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
   constexpr bool STAGE = BP::STAGE;
   double *const staged = acc + bp.max_list; // STAGE: src values of the current brick, indexed like acc
   uint32_t *const run_tab = reinterpret_cast<uint32_t *>(acc + (STAGE ? 2 : 1) * (size_t)bp.max_list);
-  uint32_t r0 = RUNS ? bp.run_off[b] : 0u;
-  int n_runs = RUNS ? (int)(bp.run_off[b + 1] - r0) : 0;
+  uint32_t r0 = RUNS ? bp.run_off[pb] : 0u;
+  int n_runs = RUNS ? (int)(bp.run_off[pb + 1] - r0) : 0;
   uint32_t run_slot = 0, run_dof = 0;
   const bool lane_ok = (ab < n2) && (c < CPT);
   const int abm = ab < n2 ? ab : ab % n2;
@@ -1727,7 +1759,10 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
   for (int i = t; i < (int)bp.max_list; i += TEAM) acc[i] = 0.0;
   __syncthreads();
 
-  auto entry = [&](uint32_t pass) { return bp.pass_cell[(uint64_t)(pass < gp_end ? pass : gp_end - 1) * CPT + slot]; };
+  auto entry = [&](uint32_t pass) {
+    const uint32_t v = pass < gp_end ? pass : gp_end - 1;           // virtual pass -> physical pass
+    return bp.pass_cell[(uint64_t)(v < npa ? pa0 + v : pb0 + (v - npa)) * CPT + slot];
+  };
   // STAGE: fill staged[0, m_) with the src values of the brick whose run table rt_ (n_runs_ runs) is in LDS: thread t takes the
   // slot pairs (2t, 2t+1) + 2 TEAM j and walks the table forward, consecutive lanes read consecutive DoFs of a run
   auto enter_block = [&](const uint32_t *rt_, int n_runs_, int m_) {
@@ -1782,13 +1817,14 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
   int nx_rounds = 1;
   auto prefetch_list = [&]() {
     if (gp + 1 == boundary && b + 1 < b1) {
-      nx_boundary = bp.pass_off[b + 2];
-      nx_o0 = bp.off[b + 1];
-      nx_o1 = bp.off[b + 2];
-      nx_rounds = bp.blk_rounds[b + 1];
+      const uint32_t p1 = blk(b + 1);
+      nx_boundary = boundary + (bp.pass_off[p1 + 1] - bp.pass_off[p1]);
+      nx_o0 = bp.off[p1];
+      nx_o1 = bp.off[p1 + 1];
+      nx_rounds = bp.blk_rounds[p1];
       if constexpr (RUNS) {
-        nx_r0 = bp.run_off[b + 1];
-        nx_r1 = bp.run_off[b + 2];
+        nx_r0 = bp.run_off[p1];
+        nx_r1 = bp.run_off[p1 + 1];
       }
     }
     if (gp + 1 == boundary) {
@@ -1968,6 +2004,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
         }
       }
       ++b;
+      if (bp.signal && b == nba) signal_part_done(true);            // the last ghost-touching brick of this workgroup is written out
       if (b < b1) {
         boundary = nx_boundary;
         o0 = nx_o0;
@@ -2030,7 +2067,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
     if (t == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) bp.stamps[(uint64_t)w * 16 + k] = ph[k];
-      bp.stamps[(uint64_t)w * 16 + 8] = gp_end - bp.pass_off[bp.wg_block[w]];
+      bp.stamps[(uint64_t)w * 16 + 8] = gp_end;
     }
   }
 }

@@ -300,9 +300,12 @@ int bp5_halo_scatter_add(bp5_mf *mf, double *v);
 int bp5_halo_zero_ghosts(bp5_mf *mf, double *v);
 /* == MatrixFree::AdditionalData::overlap_communication_computation (bp5/step-64.cu:241).  mode 1: on (the reference's setting);
  *    0: off -- the exchange stays on the handle's stream and the cell loop runs unsplit; 2 (default): the library decides.
- *    Solvers on the block kernel (fused dot products) overlap BOUNDARY-FIRST: the bricks that touch ghost DoFs run first, their rows
- *    travel to the owners on the communication stream while the interior bricks run (two launches; automatic whenever the
- *    ghost-touching bricks hold at most a third of the cells); the ghost gather of the search direction travels under the vector update.
+ *    Solvers on the block kernel (fused dot products), mode 1: BOUNDARY-FIRST -- every workgroup of the (single) launch walks its share
+ *    of the ghost-touching bricks first and counts itself in; the communication stream waits for the count (hipStreamWaitValue64),
+ *    combines the ghost rows and sends them to their owners while the same launch works through the interior bricks.  Mode 2 there:
+ *    one launch, then the ghost rows of the combine pass, the exchange on the communication stream UNDER the owned rows of the combine
+ *    pass (a transfer that runs beside the bandwidth-bound brick kernel is slow and slows it; profiles/r3).  In every mode the ghost
+ *    gather of the search direction travels under the vector update, and the results are bitwise the same.
  *    bp5_apply_distributed and the atomic kernels use the three-phase split (interior, boundary, interior): automatic from 1e6
  *    interior cells on -- it costs three launches and four cross-stream dependencies per application (profiles/r2, r3 READMEs) */
 int bp5_mf_set_overlap(bp5_mf *mf, int mode);
@@ -341,7 +344,8 @@ typedef struct {
   int dot_products_fused;  /* 1: the solve formed its dot products inside the operator kernels (bp5_mf_set_cg_fusion) */
   int exchange_schedule;   /* halo exchange of the operator applications: 0 none (one rank), 1 unsplit (gather, all cells, scatter-add),
                               2 boundary-first (ghost-touching bricks, exchange on the communication stream under the interior bricks),
-                              3 three-phase (atomic kernels / separate dot products: interior, boundary, interior)            */
+                              3 three-phase (atomic kernels / separate dot products: interior, boundary, interior),
+                              4 all bricks in one launch, ghost rows combined first, exchange under the owned-row combine pass    */
   char apply_kernel[96];   /* the operator kernel the solve launched last, as a profiler prints it (e.g.
                               "apply_block_kernel<4,false,32,1,1337344>"): what rocprofv3 rows belong to this solve               */
   /* profile=2, BP5_CG_MERGED: average HIP-event time of the phases of one iteration on the handle's stream (ms), BP5_PHASE_* */

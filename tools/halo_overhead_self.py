@@ -45,7 +45,7 @@ ap.add_argument("--weak", action="store_true", help="every rank owns 116 cell la
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--solver", choices=["merged", "plain"], default="merged")
 ap.add_argument("--cell-block", type=int, nargs=3, default=[4, 4, 4])
-ap.add_argument("--modes", default="overlapped,sequential,none", help="comma list of: overlapped, sequential, none (profiling runs take one)")
+ap.add_argument("--modes", default="auto,overlapped,launches,sequential,none", help="comma list of: overlapped (boundary-first inside one launch), launches (boundary-first, two launches), sequential, none")
 ap.add_argument("--reps", type=int, default=3)
 args = ap.parse_args()
 p, n = 4, 116
@@ -61,15 +61,17 @@ mesh = SimpleNamespace(degree=p, n=p + 1, cells=(n, n, nz), n_cells=m1.n_cells, 
                        cell_block_offsets=m1.cell_block_offsets, rank=0, n_ranks=1, h=1.0 / n, deform_amp=0.0)
 Solver = pkg.SolverCGFullMerge if args.solver == "merged" else pkg.SolverCG
 res = {}
-all_modes = {"overlapped": "slab + exchange, overlapped", "sequential": "slab + exchange, sequential", "none": "same size, one rank, no exchange"}
+all_modes = {"auto": "slab + exchange, automatic", "overlapped": "slab + exchange, overlapped", "launches": "slab + exchange, overlapped (two launches)",
+             "sequential": "slab + exchange, sequential", "none": "same size, one rank, no exchange"}
 for name in [all_modes[m] for m in args.modes.split(",")]:
+    os.environ["BP5_BOUNDARY_FIRST"] = "launches" if "two launches" in name else "signal"   # read when the handle creates its communication stream
     if name.startswith("slab"):
         comm, msh = pkg.Communicator(0, 1), mesh
     else:
         comm, msh = None, pkg.BrickMesh(p, (n, n, layers), h=1.0 / n, **kw)
     op = pkg.PoissonOperator(msh, 0, pkg.COEF_STEP64, comm=comm)
     if name.startswith("slab"):
-        op.mf_data.set_overlap(0 if name.endswith("sequential") else 1)
+        op.mf_data.set_overlap(0 if name.endswith("sequential") else 2 if name.endswith("automatic") else 1)
     b = op.assemble_rhs()
     x = op.initialize_dof_vector()
     Solver(pkg.IterationNumberControl(5, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
@@ -84,13 +86,14 @@ for name in [all_modes[m] for m in args.modes.split(",")]:
     res[name] = best
     info = op.mf_data.block_plan_info() if op.mf_data.get_apply_variant() == 56 else None
     print(f"{name}: plan (bricks, max runs, packed) {info}, dot products fused {ctl.dot_products_fused}")
+    print(f"{name}: exchange schedule {ctl.exchange_schedule}, kernel {ctl.apply_kernel}")
     print(f"{name}: {best:.3f} ms per iteration ({msh.n_owned / best / 1e6:.2f} GDoF/s), operator {ctl.operator_ms_avg:.3f} ms, "
           f"variant {op.mf_data.get_apply_variant()}, cells {msh.n_cells}, owned {msh.n_owned}, ghosts {msh.n_ghost}", flush=True)
     op.mf_data.close()
     if comm is not None:
         comm.close()
 ref = res.get("same size, one rank, no exchange")
-for k in ("slab + exchange, overlapped", "slab + exchange, sequential"):
+for k in ("slab + exchange, automatic", "slab + exchange, overlapped", "slab + exchange, overlapped (two launches)", "slab + exchange, sequential"):
     if ref is None or k not in res:
         continue
     print(f"{k}: +{(res[k] - ref) * 1e3:.0f} us per iteration ({(res[k] / ref - 1) * 100:.1f} %) over the mesh without exchange")

@@ -13,5 +13,9 @@ t0, prev_end = int(rows[i0]["Start_Timestamp"]), None
 for r in rows[i0:i0 + n]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = "" if prev_end is None else f"{(s - prev_end) / 1e3:8.1f}"
-    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f} us  gap {gap:>8}  q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:90]}")
+    try:
+        wgs = f"{int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1):5d} wg"
+    except (KeyError, ValueError):
+        wgs = "    ? wg"
+    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f} us  gap {gap:>8}  q{r.get('Queue_Id', '?')} {wgs}  {r['Kernel_Name'][:90]}")
     prev_end = max(e, prev_end or e)
