@@ -139,10 +139,12 @@ def default_cell_block(p, cells_per_rank):
     """Cell order / DoF numbering are the host's choice (the reference's MatrixFree::reinit reorders cells too): bricks sized for the
     block kernel's LDS accumulator, parity-class order inside a brick, brick-major DoF numbering -> the library picks its deterministic
     block kernel.  Small problems (config 2's 54^3; the 116x116x14.5 slab of one of 8 ranks): 4x4x2 bricks give the persistent
-    workgroups twice as many bricks to balance (profiles/r2: 0.427 vs 0.439 ms per iteration at 54^3).  p = 2, 5, 8: the atomic pencil
-    kernel is still ahead of the block kernel (profiles/r2) and gains 3-6 % from 8x8x8 parity-class bricks (p = 2: lexicographic)."""
+    workgroups twice as many bricks to balance (profiles/r2: 0.427 vs 0.439 ms per iteration at 54^3).  p = 2, 5 (round 3: n^2 lanes
+    per cell, 28 / 7 cells per pass -- bricks whose parity classes fill a pass: 8x8x4, 6x4x2) run the deterministic block kernel too, on
+    par with the atomic pencil kernel (profiles/r3 i_*); p = 8: the atomic pencil kernel is still 17 % ahead of the block kernel and
+    gains 3-6 % from 8x8x8 parity-class bricks (`--cell-block 2 2 2 --apply-variant 56` runs the deterministic kernel there)."""
     small = cells_per_rank < 400000
-    return {1: (8, 8, 8), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (8, 8, 8), 6: (4, 4, 2), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
+    return {1: (8, 8, 8), 2: (8, 8, 4), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (6, 4, 2), 6: (4, 4, 2), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
 
 
 def main():

@@ -152,10 +152,23 @@ struct bp5_mf {
   size_t n_local() const { return (size_t)n_owned + n_ghost; }
 };
 
-// Lanes per cell of the block-assembled kernel's default shape (one transpose tile per cell used field after field: the lanes
-// of a cell must sit in one wave, so LPC divides 64).  0 = the degree has no such shape (p = 8: 81
-// lanes per cell do not fit a wave, atomic pencil kernel).  Cells per pass = 256 / LPC.
-constexpr int block_lpc(int degree) { return degree == 1 ? 4 : degree == 2 || degree == 3 ? 16 : degree == 4 ? 32 : degree >= 5 && degree <= 7 ? 64 : degree == 8 ? 128 : 0; }
+// Lanes per cell of the block-assembled kernel's default shape (one transpose tile per cell used field after field; when the lanes
+// of a cell sit in one wave -- LPC divides 64 -- the tile exchanges are wave-local, else they use the workgroup barrier).
+// Cells per pass = 256 / LPC.
+// p = 2, 5, 8 (round 3): n^2 = 9 / 36 / 81 lanes per cell -- cells span waves, so the tile exchanges go through the workgroup barrier,
+// but 28 / 7 / 3 cells share a pass and hardly a lane idles (round 2: 16 / 64 / 128 lanes per cell, 44 / 44 / 37 % idle).  Same-box A/B
+// at the config-4 sizes (profiles/r3 i_*): p = 2 18.1 against 17.7 GDoF/s, p = 5 (6x4x2 bricks) 25.5 against 23.1, p = 8 23.2 against
+// 19.7.  The macros are the A/B knobs (-DBP5_LPC_P2=16 -DBP5_LPC_P5=64 -DBP5_LPC_P8=128 rebuilds round 2's shapes).
+#ifndef BP5_LPC_P2
+#define BP5_LPC_P2 9
+#endif
+#ifndef BP5_LPC_P5
+#define BP5_LPC_P5 36
+#endif
+#ifndef BP5_LPC_P8
+#define BP5_LPC_P8 81
+#endif
+constexpr int block_lpc(int degree) { return degree == 1 ? 4 : degree == 2 ? BP5_LPC_P2 : degree == 3 ? 16 : degree == 4 ? 32 : degree == 5 ? BP5_LPC_P5 : degree == 6 || degree == 7 ? 64 : degree == 8 ? BP5_LPC_P8 : 0; }
 inline int block_cpt(const bp5_mf *mf) { return block_lpc(mf->degree) ? 256 / block_lpc(mf->degree) : 8; }
 
 template <typename T>

@@ -895,10 +895,14 @@ def test_medium_size_against_c_oracle():
     # the deterministic block kernel on the other degrees at the BASELINE sizes: config 5 (p = 6, 61^3, deformed, 49 430 863 DoFs) and
     # config 4 (~5e7 DoFs) for p = 2, 3, 5, 7 -- bricks sized for the LDS accumulator, partial bricks at the mesh edges
     (6, (61, 61, 61), 0, 0.05, 1, dict(cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1), 56),
-    (5, (73, 73, 73), 0, 0.03, 1, dict(cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1), 56),
+    (5, (73, 73, 73), 0, 0.03, 1, dict(cell_block=(6, 4, 2), dof_numbering=1, cell_block_order=1), 56),
     (7, (52, 52, 52), 1, 0.03, 1, dict(cell_block=(4, 2, 2), dof_numbering=1, cell_block_order=1), 56),
     (3, (122, 122, 122), 0, 0.03, 1, dict(cell_block=(8, 4, 4), dof_numbering=1, cell_block_order=1), 56),
     (2, (184, 184, 184), 0, 0.0, 1, dict(cell_block=(8, 8, 4), dof_numbering=1, cell_block_order=1), 56),
+    # ... and its end points at full size: p = 1 (367^3 cells, 49 836 032 DoFs) and p = 8 (46^3 cells, 50 243 409 DoFs; 81 lanes per cell:
+    # three cells per pass, cells that span waves)
+    (1, (367, 367, 367), 0, 0.0, 1, dict(cell_block=(8, 8, 8), dof_numbering=1, cell_block_order=1), 56),
+    (8, (46, 46, 46), 0, 0.03, 1, dict(cell_block=(2, 2, 2), dof_numbering=1, cell_block_order=1), 56),
     # maximum sizes: five times the headline problem on one GPU (513 922 401 DoFs, half the 2^30 range of the local 32-bit indices; 64-bit
     # offsets into the 49 GB metric array); profiles/r2 holds a bench line at 1 003 003 001 DoFs
     (4, (200, 200, 200), 0, 0.0, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56)])
