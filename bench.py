@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--coefficient", choices=["one", "step64"], default="step64")
     ap.add_argument("--deform", type=float, default=None)
     ap.add_argument("--variant", choices=["merged", "plain"], default="merged")
+    ap.add_argument("--operator", choices=["poisson", "helmholtz"], default="poisson",
+                    help="poisson: BP5 (the metric); helmholtz: step-64's (grad v, grad u) + (v, a u) on the native fused kernel (SURVEY 8 f1: seven planes, G = 7)")
     ap.add_argument("--apply-variant", type=int, default=0)
     ap.add_argument("--overlap", type=int, choices=[0, 1, 2], default=2,
                     help="N > 1: halo-exchange schedule of the timed solve (bp5_mf_set_overlap): 0 unsplit, 1 boundary-first, 2 the library decides (exchange under the owned-row combine)")
@@ -251,7 +253,7 @@ def main():
     cells = base if strong else (base[0], base[1], base[2] * world)   # z-slabs either way
     quad = pkg.QUAD_GAUSS if args.quadrature == "gauss" else pkg.QUAD_GLL
     km = pkg.COEF_STEP64 if args.coefficient == "step64" else pkg.COEF_ONE
-    G = 6 if args.geometry == "merged6" else 1
+    G = (7 if args.operator == "helmholtz" else 6) if args.geometry == "merged6" else 1
     Solver = pkg.SolverCGFullMerge if args.variant == "merged" else pkg.SolverCG
     precond = pkg.DiagonalMatrix()
 
@@ -270,8 +272,11 @@ def main():
                           "n_global_dofs": int(mesh.n_global_dofs), "neighbors": [int(r) for r in mesh.neighbor_rank]}), flush=True)
         return
     try:
-        op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
-                                 geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
+        if args.operator == "helmholtz":
+            op = pkg.HelmholtzOperator(mesh, quad, km, device=local_rank, comm=comm)
+        else:
+            op = pkg.PoissonOperator(mesh, quad, km, device=local_rank, comm=comm,
+                                     geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
         op.mf_data.set_apply_variant(args.apply_variant)
         op.mf_data.set_overlap(args.overlap)
         b = op.assemble_rhs()
@@ -401,7 +406,8 @@ def main():
                 continue
             nq = CONFIG_SIZES[q]
             mq, _, _ = build(q, (nq, nq, nq))
-            oq = pkg.PoissonOperator(mq, quad, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
+            oq = pkg.HelmholtzOperator(mq, quad, km, device=local_rank) if args.operator == "helmholtz" else \
+                pkg.PoissonOperator(mq, quad, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
             bq, xq = oq.assemble_rhs(), oq.initialize_dof_vector()
             timed_solve(3, oq, xq, bq)
             cq, dq = timed_solve(max(10, min(args.steps, 30)), oq, xq, bq)
@@ -420,7 +426,7 @@ def main():
         B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
         ev = op.mf_data.get_apply_variant()
-        key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}"
+        key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}" + ("_helmholtz" if args.operator == "helmholtz" else "")
         block_kernel = ctl.apply_kernel.startswith("apply_block_kernel")
         # SolverCGFullMerge on the packed block kernel: the dot products of update_b (contract: "dot reads p,r,v",
         # 24 B/DoF of the formula's 88) are formed inside the operator's write-out (reported by the solve itself)
@@ -433,7 +439,7 @@ def main():
         kname = ctl.apply_kernel or f"apply variant {ev}"     # reported by the solve: the kernel it launched, as a profiler prints it
         tr = None
         if world == 1 and not args.no_traffic_pass and not args.rehearsal:
-            wl = ["--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
+            wl = ["--operator", args.operator, "--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
                   "--variant", args.variant, "--geometry", args.geometry, "--apply-variant", str(args.apply_variant),
                   "--cells", str(cells[0]), str(cells[1]), str(cells[2]), "--cell-block", str(block[0]), str(block[1]), str(block[2])]
             tr = live_traffic(kname, wl)
@@ -446,7 +452,8 @@ def main():
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": iters, "warmup": args.warmup,
             "ms_per_step": dt / max(iters, 1) * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
+            "config": {"workload": ("step-64 Helmholtz operator (NOT the BP5 metric's operator; SURVEY 8 f1), " if args.operator == "helmholtz" else "") +
+                                   f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
                        "baseline_config": args.config if args.config else (3 if (p == 4 and base == (116, 116, 116)) else None),

@@ -14,6 +14,7 @@ QUAD_GAUSS, QUAD_GLL = 0, 1
 COEF_ONE, COEF_STEP64 = 0, 1
 CG_PLAIN, CG_MERGED = 0, 1
 GEOM_MERGED6, GEOM_AFFINE = 0, 1
+OP_POISSON, OP_HELMHOLTZ = 0, 1
 UNIQUE_ID_BYTES = 128
 
 

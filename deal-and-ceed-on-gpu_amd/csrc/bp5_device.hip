@@ -205,7 +205,17 @@ extern "C" int bp5_mf_sync(bp5_mf *mf)
 extern "C" int bp5_mf_coef_size(const bp5_mf *mf, size_t *n)
 {
   if (!mf || !n) return fail(BP5_ERR_INVALID, "null argument");
-  *n = (size_t)6 * mf->n_cells * mf->n3;
+  *n = (size_t)mf->n_planes() * mf->n_cells * mf->n3;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_set_operator(bp5_mf *mf, int op)
+{
+  if (!mf || (op != BP5_OP_POISSON && op != BP5_OP_HELMHOLTZ)) return fail(BP5_ERR_INVALID, "unknown operator");
+  if (op == BP5_OP_HELMHOLTZ && (mf->has_hanging || mf->geometry_mode == BP5_GEOM_AFFINE))
+    return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs a conforming mesh and the six-plane geometry (hanging nodes: the facade's FEEvaluation)");
+  if (op == BP5_OP_HELMHOLTZ && mf->apply_variant != 0 && mf->apply_variant != 56) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator runs apply variants 0 and 56");
+  mf->operator_kind = op;
+  mf->auto_block = -1; // (decided per operator: the Helmholtz build of the block kernel runs two workgroups per CU)
   return BP5_OK;
 }
 // the variants of the product library: every one of them computes the operator (they differ in launch shape, staging and
@@ -235,6 +245,7 @@ extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
     return BP5_OK;
   }
   if (v == 90) return fail(BP5_ERR_INVALID, "apply variant 90 is the hanging-node kernel: the mesh has no constraint masks");
+  if (mf->operator_kind == BP5_OP_HELMHOLTZ && v != 0 && !(v == 56 && block_lpc(mf->degree) != 0)) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator runs apply variants 0 (pencil kernel) and 56 (block kernel)");
 #ifndef BP5_TIMING_BUILDS
   if (!product_variant(mf->degree, v)) return fail(BP5_ERR_INVALID, "unknown (degree, apply variant): timing-only builds live in libbp5_timing.so");
 #endif
@@ -305,6 +316,7 @@ extern "C" int bp5_mf_set_geometry_mode(bp5_mf *mf, int mode)
   if (!mf) return fail(BP5_ERR_INVALID, "null handle");
   if (mode != BP5_GEOM_MERGED6 && mode != BP5_GEOM_AFFINE) return fail(BP5_ERR_INVALID, "unknown geometry mode");
   HIP_TRY(hipSetDevice(mf->device));
+  if (mode == BP5_GEOM_AFFINE && mf->operator_kind == BP5_OP_HELMHOLTZ) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs the six-plane geometry");
   if (mode == BP5_GEOM_AFFINE && !mf->d_scalar_plane) {
     double *sp = nullptr, *gc = nullptr, *dev = nullptr;
     const size_t nq = (size_t)mf->n_cells * mf->n3;
@@ -338,13 +350,15 @@ extern "C" int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef)
   GeomOut o{};
   o.coef = coef;
   o.plane_stride = mf->coef_plane_stride; o.cell_stride = mf->coef_cell_stride;
+  o.helmholtz = mf->operator_kind == BP5_OP_HELMHOLTZ;
+  if (o.helmholtz && mf->coef_cell_stride != (uint64_t)mf->n3) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs the plane-major metric layout");
   DISPATCH_N(launch_geometry, mf, o);
 }
 
 template <int n>
 static int launch_permute(bp5_mf *mf, const double *in, double *out)
 {
-  const uint64_t total = (uint64_t)6 * mf->n_cells * mf->n3;
+  const uint64_t total = (uint64_t)mf->n_planes() * mf->n_cells * mf->n3;
   hipLaunchKernelGGL(metric_permute_kernel<n>, dim3(2048), dim3(256), 0, mf->stream, in, out, total, (uint64_t)mf->n_cells, mf->coef_plane_stride,
                      mf->coef_cell_stride);
   KERNEL_CHECK();
@@ -611,6 +625,25 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
   if (mf->has_hanging) return 90;
   const int v = mf->apply_variant;
   if (v != 0) return v;
+  if (mf->operator_kind == BP5_OP_HELMHOLTZ) { // pencil kernel, or the block kernel under the same conditions as below
+    uint32_t hb0, hb1;
+    if (!block_lpc(mf->degree) || mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &hb0, &hb1)) return 0;
+    if (mf->auto_block < 0) {
+      bp5_mf::DevPlan *dp = nullptr;
+      mf->auto_block = 0;
+      if (get_plan_raw(mf, -block_cpt(mf), &dp, 64) == BP5_OK && dp->packed) {
+        const int n = mf->degree + 1;
+        const size_t lds = ((size_t)block_cpt(mf) * (n * (n * n + 1) + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
+        if (!mf->n_cus) {
+          hipDeviceProp_t prop;
+          if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
+        }
+        mf->auto_block = lds * 2 <= 160 * 1024 && dp->n_groups >= 2u * (uint32_t)std::max(mf->n_cus, 1);
+      }
+    }
+    if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (hb1 - hb0) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return 0;
+    return mf->auto_block ? 56 : 0;
+  }
   if ((mf->degree == 1 || mf->degree == 3) && mf->h_block_off.empty()) {
     if (mf->geometry_mode == BP5_GEOM_AFFINE) return 0;
     if (mf->auto_team < 0) { // an irregular cell order can exhaust the team plan's rounds: then the atomic pencil kernel
@@ -761,6 +794,7 @@ extern "C" int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag
   if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !diag) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(mf->device));
   if (mf->has_hanging && mf->geometry_mode == BP5_GEOM_AFFINE) return fail(BP5_ERR_UNSUPPORTED, "bp5_compute_diagonal on meshes with hanging nodes in the affine geometry mode");
+  if (mf->operator_kind == BP5_OP_HELMHOLTZ) return fail(BP5_ERR_UNSUPPORTED, "bp5_compute_diagonal: Poisson operator only");
   HIP_TRY(hipMemsetAsync(diag, 0, mf->n_local() * sizeof(double), mf->stream));
   if (mf->n_cells) BP5_TRY(diagonal_dispatch(mf, coef, diag));
   if (mf->comm && !mf->neighbors.empty()) { // ghost contributions to their owners

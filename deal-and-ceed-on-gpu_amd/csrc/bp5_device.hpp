@@ -50,6 +50,8 @@ struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
+  int operator_kind = 0; // BP5_OP_POISSON | BP5_OP_HELMHOLTZ (seven planes: six merged + the mass plane a JxW)
+  int n_planes() const { return operator_kind == BP5_OP_HELMHOLTZ ? 7 : 6; }
   uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
   bool combine_csr = false; // A/B: per-DoF CSR combine kernel instead of the run-length one
   int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
@@ -277,7 +279,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
     mf->n_cus = prop.multiProcessorCount;
   }
-  const int wg_per_cu = ((ABL & 2048) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int wg_per_cu = ((ABL & 2048) && !(ABL & 8388608) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (the Helmholtz build: two per CU, registers)
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
@@ -499,6 +501,36 @@ inline int launch_affine(bp5_mf *mf, const double *src, double *dst, uint32_t c0
 template <int DEG>
 int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
 {
+  if (mf->operator_kind == BP5_OP_HELMHOLTZ) {
+    // step-64's Helmholtz operator (step-64/step-64.cu:154-160,201-219) as a build of the same fused kernels: the degree's default pencil
+    // shape (any mesh), or the deterministic block kernel on cell bricks (variant 56; with the CG dot products fused when the solver asks)
+    if (mf->has_hanging || mf->geometry_mode == BP5_GEOM_AFFINE) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs a conforming mesh and the six-plane geometry");
+    const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
+    constexpr int HELM = 8388608;
+    if (mf->apply_variant == 56) {
+      if constexpr (block_lpc(DEG) != 0) {
+        constexpr int LPCB = block_lpc(DEG);
+        if (c1 <= c0) { if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream)); return BP5_OK; }
+        if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
+        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+        bp5_mf::DevPlan *dp_ = nullptr;
+        BP5_TRY(get_plan_raw(mf, -(256 / LPCB), &dp_));
+        if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 56 needs packed indices (<= 128 runs per cell block)");
+        if (mf->fuse.on)
+          return coll_ ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HELM>(mf, coef, src, dst, overwrite)
+                       : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HELM>(mf, coef, src, dst, overwrite);
+        return coll_ ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + HELM>(mf, coef, src, dst, overwrite)
+                     : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + HELM>(mf, coef, src, dst, overwrite);
+      }
+    }
+    if (mf->apply_variant != 0) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator runs apply variants 0 (pencil kernel) and 56 (block kernel)");
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    if (c1 <= c0) return BP5_OK;
+    constexpr int n2e = (DEG + 1) * (DEG + 1);
+    constexpr int TWE = DEG <= 3 ? 1 : 4, TPBE = DEG <= 3 ? 4 : 1;
+    return coll_ ? launch_apply_t<DEG, true, TWE, n2e, TPBE, true, HELM>(mf, coef, src, dst, c0, c1)
+                 : launch_apply_t<DEG, false, TWE, n2e, TPBE, true, HELM>(mf, coef, src, dst, c0, c1);
+  }
   if (mf->has_hanging) {
     // 2:1 refined meshes: the degree's default pencil shape with the hanging-node fix-up after the gather and its adjoint
     // before the (atomic) scatter -- variant 90, the only operator kernel that honours constraint masks

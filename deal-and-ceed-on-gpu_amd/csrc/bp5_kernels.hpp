@@ -334,7 +334,14 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
   // ---- metric planes (x-owner: a_ = j, b_ = k; registers hold i), layout [c][cell][i][j+n k]
   const double *cf = a.coef + cell * a.cell_stride; // cell base; lane offsets through coef_off / load_pencil
   constexpr bool AFFINE = (ABL & 1024) != 0; // affine geometry: one scalar plane + six per-cell numbers
-  double S[(PF && !AFFINE) ? 6 : 1][n];
+  // HELM: step-64's Helmholtz operator (grad v, grad u) + (v, a u) (step-64/step-64.cu:154-160,201-219): evaluate(true, true) /
+  // integrate(true, true) cost ONE more 1-D contraction each way (the value path shares the y- and z-contractions with the x-derivative),
+  // submit_value(a * get_value()) one more plane: a(x_q) JxW behind the six merged planes
+  constexpr bool HELM = (ABL & 8388608) != 0;
+  static_assert(!HELM || (PF && !AFFINE), "Helmholtz build: prefetched planes, six-plane geometry");
+  constexpr int NPL = HELM ? 7 : 6;
+  double S[(PF && !AFFINE) ? NPL : 1][n];
+  double um[HELM ? n : 1]; // HELM: u at the quadrature points of this lane's x-pencil, then a JxW u
   double Gc[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (AFFINE) {
     load_pencil<n>(cf, abm, S[0]);
@@ -342,7 +349,7 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     for (int pl = 0; pl < 6; ++pl) Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
   } else if constexpr (PF) {
 #pragma unroll
-    for (int pl = 0; pl < 6; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
       if constexpr (ABL & 2) {
 #pragma unroll
         for (int i = 0; i < n; ++i) S[pl][i] = 1.0 + pl + i + 1e-3 * abm;
@@ -390,6 +397,7 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     MV_D(sh.D, r1, g0);
     MV_N(sh.N, r2, g1);
     MV_N(sh.N, r3, g2);
+    if constexpr (HELM) MV_N(sh.N, r1, um); // value_at_quad_pts: (N x N x N) u
   } else {
     // collocation: g0 = Dx u, g1 = Dy u, g2 = Dz u
     double gz[n];
@@ -416,6 +424,10 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
       g2[i] = TL(2, b_, a_, i);
     }
     MV_D(sh.D, r1, g0);
+    if constexpr (HELM) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) um[i] = r1[i]; // collocation: the nodal values are the values at the quadrature points
+    }
   }
 
   // ---- quadrature-point operation: t = S ghat (symmetric 3x3, bp5/step-64.cu:166-177)
@@ -439,6 +451,7 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
     g0[i] = s00 * x0 + s01 * x1 + s02 * x2;
     g1[i] = s01 * x0 + s11 * x1 + s12 * x2;
     g2[i] = s02 * x0 + s12 * x1 + s22 * x2;
+    if constexpr (HELM) um[i] *= S[6][i]; // submit_value(coef * get_value(q)) with JxW folded into the plane (step-64/step-64.cu:158)
   }
 
   // ---- integrate (transpose sequence)
@@ -449,6 +462,7 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
   } else if constexpr (!COLL) {
     double e1[n], e2[n], e3[n];
     MV_DT(sh.D, g0, e1);
+    if constexpr (HELM) MV_NT_ADD(sh.N, um, e1); // integrate_value shares the y- and z-contractions with the x-derivative
     MV_NT(sh.N, g1, e2);
     MV_NT(sh.N, g2, e3);
     team_sync<TW>();
@@ -482,6 +496,10 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
   } else {
     double e1[n];
     MV_DT(sh.D, g0, e1);
+    if constexpr (HELM) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) e1[i] += um[i];
+    }
     team_sync<TW>();
     if (active) {
 #pragma unroll
@@ -1182,11 +1200,11 @@ struct BlockPlan {
 };
 
 // register set of one pass (cell ids, positions, gathered values, metric)
-template <int n, bool AFFINE>
+template <int n, bool AFFINE, int NPL = 6>
 struct PassRegs {
   uint16_t ps[n];
   double u[n];
-  double S[AFFINE ? 1 : 6][n]; // affine: one scalar plane ...
+  double S[AFFINE ? 1 : NPL][n]; // affine: one scalar plane ... (NPL = 7: the Helmholtz build's mass plane behind the six merged ones)
   double Gc[AFFINE ? 6 : 1];   // ... and the cell's constant K K^T
   uint32_t idx[n];
   uint32_t ent; // pass_cell entry
@@ -1220,7 +1238,11 @@ struct BlockPass {
   // SINGLE: the metric of a pass is loaded at the top of that pass (as in apply_pencil_kernel) and only the
   // indices / gathered values are prefetched one pass ahead: ~60 fewer VGPRs -> three workgroups per CU
   static constexpr bool SINGLE = (ABL & 2048) != 0;
-  using R = PassRegs<n, AFFINE>;
+  // HELM: step-64's Helmholtz operator, see apply_pencil_kernel (one more contraction each way, one more plane: a(x_q) JxW)
+  static constexpr bool HELM = (ABL & 8388608) != 0;
+  static constexpr int NPL = HELM ? 7 : 6;
+  static_assert(!HELM || (!AFFINE && (ABL & 8192) != 0), "Helmholtz build: six-plane geometry, sequential tiles");
+  using R = PassRegs<n, AFFINE, NPL>;
   // all lanes of a cell slot sit in one wave when LPC divides 64: the tile exchanges then need no block barrier
   static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
   // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
@@ -1263,7 +1285,7 @@ struct BlockPass {
       for (int pl = 0; pl < 6; ++pl) r.Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
     } else {
 #pragma unroll
-      for (int pl = 0; pl < 6; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
         if constexpr (ABL & 2) {
 #pragma unroll
           for (int i = 0; i < n; ++i) r.S[pl][i] = 1.0 + pl + i;
@@ -1305,6 +1327,7 @@ struct BlockPass {
       const bool act = cur.active;
       double(&uu)[n] = cur.u;
       double q0[n], q1[n], q2[n];
+      double um[HELM ? n : 1]; // HELM: u at this lane's quadrature points, then a JxW u
       if constexpr (!COLL) {
         double aN[n], aD[n], vN[n], vD[n];
         MV_N(sh.N, uu, aN);
@@ -1356,6 +1379,7 @@ struct BlockPass {
         MV_D(sh.D, r1, q0);
         MV_N(sh.N, r2, q1);
         MV_N(sh.N, r3, q2);
+        if constexpr (HELM) MV_N(sh.N, r1, um);
       } else {
         double gz[n], vN[n], c2[n], r1[n];
         MV_D(sh.D, uu, gz);
@@ -1387,6 +1411,10 @@ struct BlockPass {
         for (int i = 0; i < n; ++i) q2[i] = T1(b_, a_, i);
         tile_sync();
         MV_D(sh.D, r1, q0);
+        if constexpr (HELM) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) um[i] = r1[i];
+        }
       }
       BP5_STAMP(1)
       if constexpr (!PACK) issue_gather(a, nxt); // PACK: after the pass, once the next block's run table is parked
@@ -1407,12 +1435,18 @@ struct BlockPass {
         // fused CG: src . (A src) is the sum over cells and quadrature points of ghat^T S ghat -- everything is in
         // registers here, the dot product costs no memory traffic at all
         if constexpr ((ABL & 1048576) != 0) { if (act) energy += x0 * q0[i] + x1 * q1[i] + x2 * q2[i]; }
+        if constexpr (HELM) {
+          const double uq = um[i];
+          um[i] = cur.S[6][i] * uq; // submit_value(coef * get_value(q)), JxW folded into the plane
+          if constexpr ((ABL & 1048576) != 0) { if (act) energy += uq * um[i]; }
+        }
       }
       BP5_STAMP(3)
       double yy[n];
       if constexpr (!COLL) {
         double e1[n], e2[n], e3[n], w1[n], w2[n], w3[n];
         MV_DT(sh.D, q0, e1);
+        if constexpr (HELM) MV_NT_ADD(sh.N, um, e1);
         MV_NT(sh.N, q1, e2);
         MV_NT(sh.N, q2, e3);
         if (act) {
@@ -1464,6 +1498,10 @@ struct BlockPass {
       } else {
         double e1[n], w1[n], w2[n], z2[n];
         MV_DT(sh.D, q0, e1);
+        if constexpr (HELM) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) e1[i] += um[i];
+        }
         // y-direction: w1 = e1 + D^T q1 (both re-oriented x-owner -> y-owner)
         if (act) {
 #pragma unroll
@@ -1679,7 +1717,7 @@ struct BlockPass {
 };
 
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 8388608)) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;
@@ -1786,7 +1824,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4) ? 3 : 2) apply_b
   // at the top of pass q and first waited for inside pass q+1
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
   if constexpr (ABL & 4096) tprev = stamp_now();
-  PassRegs<n, (ABL & 1024) != 0> A, B;
+  typename BP::R A, B;
   A.ent = entry(gp);
   B.ent = entry(gp + 1);
   BP::issue_loads(a, bp, A, abm, lane_ok, true);
@@ -2137,6 +2175,9 @@ struct GeomOut {
   uint32_t n_cells;
   const uint32_t *hang_mask; // NULL: conforming mesh
   const double *hang_I;
+  // Helmholtz operator (step-64/step-64.cu:99-118,154-160): planes 0-5 = JxW K K^T (Laplace part, coefficient 1), plane 6 = a(x_q) JxW
+  // (VaryingCoefficientFunctor's coef with JxW folded in); coef then holds SEVEN planes
+  int helmholtz;
 };
 
 __device__ __forceinline__ double kappa_eval(int mode, double x, double y, double z)
@@ -2193,8 +2234,10 @@ __global__ void __launch_bounds__(n *n *n) geometry_kernel(const uint32_t *l2g, 
     const double *w = tab + 2 * n2;
     const double jxw = fabs(det) * w[i] * w[j] * w[k];
     if (o.coef) {
-      const double s = jxw * kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
+      const double kap = kappa_eval(kappa_mode, xq[0], xq[1], xq[2]);
+      const double s = o.helmholtz ? jxw : jxw * kap;
       double *c = o.coef + cell * o.cell_stride + coef_off<n>(i, j + n * k); // pair layout (coef_off)
+      if (o.helmholtz) c[6 * o.plane_stride] = jxw * kap;
       c[0 * o.plane_stride] = s * (K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2]);
       c[1 * o.plane_stride] = s * (K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2]);
       c[2 * o.plane_stride] = s * (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]);

@@ -148,6 +148,10 @@ class MatrixFree:
     def set_apply_variant(self, v):
         _lib.check(_lib.lib().bp5_mf_set_apply_variant(self.handle, int(v)))
 
+    def set_operator(self, op):
+        """OP_POISSON (bp5/step-64.cu:147-194, default) or OP_HELMHOLTZ (step-64/step-64.cu:154-160,201-219: seven planes)."""
+        _lib.check(_lib.lib().bp5_mf_set_operator(self.handle, int(op)))
+
     def set_block_workgroups(self, n):
         _lib.check(_lib.lib().bp5_mf_set_block_workgroups(self.handle, int(n)))
 
@@ -248,6 +252,23 @@ class PoissonOperator:
         r = C.c_double()
         _lib.check(_lib.lib().bp5_l2_norm_solution(self.mf_data.handle, _ptr(u, self.mf_data.n_local), C.byref(r)))
         return r.value
+
+
+class HelmholtzOperator(PoissonOperator):
+    """== Step64::HelmholtzOperator<3,fe_degree>, step-64/step-64.cu:233-305: (grad v, grad u) + (v, a(x) u) with
+    a = 10 / (0.05 + 2 |x|^2) (VaryingCoefficientFunctor, :99-118) as the library's native fused kernel
+    (bp5_mf_set_operator(BP5_OP_HELMHOLTZ)): `coef` holds the six merged planes and the mass plane a JxW.  vmult, the solvers
+    (cg.solve(A, x, b, P): the PoissonOperator branch of Solver.solve -- same handle, same entry points) and the halo exchange
+    are the ones of the Poisson operator."""
+
+    def __init__(self, mesh, quadrature=QUAD_GAUSS, coefficient=1, device=0, comm=None, stream=None):
+        self.mf_data = MatrixFree().reinit(mesh, quadrature, coefficient, device, stream, comm)
+        self.mf_data.set_operator(_lib.OP_HELMHOLTZ)
+        self.geometry = 0
+        self.coef = self.mf_data.evaluate_coefficients()
+        self.n_owned_cells = mesh.n_cells
+        self.do_zero_out = True
+        self.distributed = comm is not None and comm.n_ranks > 1
 
 
 class Vector:

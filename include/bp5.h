@@ -178,7 +178,19 @@ int bp5_mf_destroy(bp5_mf *mf);
 int bp5_mf_set_stream(bp5_mf *mf, void *hip_stream);
 int bp5_mf_sync(bp5_mf *mf); /* hipStreamSynchronize */
 
-/* number of doubles of the merged-metric array: 6 * n_cells * (p+1)^3  (bp5/step-64.cu:253-254) */
+/* Which operator the handle applies (bp5_apply*, bp5_cg_solve, all exchange schedules, fused dot products):
+ *   BP5_OP_POISSON    (default) LocalPoissonOperator, bp5/step-64.cu:147-194:  (grad v, kappa grad u), six merged planes;
+ *   BP5_OP_HELMHOLTZ  step-64's LocalHelmholtzOperator + HelmholtzOperatorQuad (step-64/step-64.cu:154-160,201-219):
+ *                     (grad v, grad u) + (v, a(x) u) -- evaluate(true, true), submit_value(a * get_value()) +
+ *                     submit_gradient(get_gradient()), integrate(true, true) -- as a native fused kernel: the value path costs one
+ *                     more 1-D contraction each way and one more plane.  The metric array then holds SEVEN planes: the six merged
+ *                     planes JxW K K^T (coefficient 1) and the mass plane a(x_q) JxW, a = the handle's BP5_COEF_* function
+ *                     (VaryingCoefficientFunctor, step-64/step-64.cu:99-118, with JxW folded in): G = 7 doubles per q-point.
+ *                     Conforming meshes, BP5_GEOM_MERGED6; apply variants 0 (pencil kernel) and 56 (block kernel on cell bricks).
+ * Set before bp5_mf_coef_size / bp5_mf_compute_merged_metric. */
+enum { BP5_OP_POISSON = 0, BP5_OP_HELMHOLTZ = 1 };
+int bp5_mf_set_operator(bp5_mf *mf, int op);
+/* number of doubles of the merged-metric array: 6 * n_cells * (p+1)^3  (bp5/step-64.cu:253-254); 7 planes for BP5_OP_HELMHOLTZ */
 int bp5_mf_coef_size(const bp5_mf *mf, size_t *n_doubles);
 
 /* == mf_data.evaluate_coefficients(JacobianFunctor), bp5/step-64.cu:84-114,256-258:

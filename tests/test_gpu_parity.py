@@ -1275,6 +1275,155 @@ def test_block_kernel_behind_the_halo_exchange(variant, neighbours):
     op.mf_data.close()
     comm.close()
 
+# ------------------------------------------------------------------ native Helmholtz operator
+def _helmholtz_oracle(pr):
+    c = pr.mesh.constrained.astype(np.int64)
+
+    def A(s):                                   # HelmholtzOperator::vmult, step-64/step-64.cu:283-300
+        d = O.apply_helmholtz_cells(pr.mesh, pr.N, pr.D, pr.w, s)
+        d[c] = s[c]
+        return d
+    return A
+
+
+@pytest.mark.parametrize("p,quad,cells,amp", [(1, 0, (5, 4, 3), 0.03), (2, 0, (4, 3, 3), 0.03), (2, 1, (3, 3, 2), 0.0), (3, 0, (3, 3, 2), 0.04), (3, 1, (3, 2, 2), 0.04),
+                                              (4, 0, (3, 2, 2), 0.04), (4, 1, (3, 2, 2), 0.0), (5, 0, (2, 2, 2), 0.03), (6, 1, (2, 2, 2), 0.03), (7, 0, (2, 2, 1), 0.03),
+                                              (8, 0, (2, 1, 2), 0.02), (8, 1, (2, 2, 1), 0.0)])
+def test_native_helmholtz_operator_pencil_kernel(p, quad, cells, amp):
+    """bp5_mf_set_operator(BP5_OP_HELMHOLTZ): step-64's (grad v, grad u) + (v, a u) (LocalHelmholtzOperator + HelmholtzOperatorQuad,
+    step-64/step-64.cu:154-160,201-219) as a build of the fused pencil kernel -- evaluate(true, true) / integrate(true, true) cost one more
+    contraction each way, the coefficient a(x_q) JxW is the seventh plane -- against the oracle's restatement, every degree, both
+    quadratures, deformed cells; accumulate mode; both solvers."""
+    torch = _t()
+    pr = O.Problem(p, cells, quad, h=0.25, deform_amp=amp)
+    mesh = pkg.BrickMesh(p, cells, h=0.25, deform_amp=amp)
+    op = pkg.HelmholtzOperator(mesh, quad, pkg.COEF_STEP64)
+    mf = op.mf_data
+    assert mf.coef_size() == 7 * mesh.n_cells * (p + 1) ** 3 and mf.get_apply_variant() == 0
+    # the seven planes: six merged Laplace planes with coefficient 1, then a JxW
+    K, JxW, xq = O.jacobians(pr.mesh, pr.N, pr.D, pr.w)
+    got = mf.coef_reference_layout(op.coef).cpu().numpy().reshape(7, mesh.n_cells, -1)
+    ref6 = O.merged_metric(pr.mesh, pr.N, pr.D, pr.w, O.kappa_none)
+    assert np.abs(got[:6] - ref6).max() < 1e-12 * np.abs(ref6).max()
+    mass = O.kappa_step64(xq) * JxW
+    assert np.abs(got[6] - mass.reshape(mesh.n_cells, -1)).max() < 1e-12 * np.abs(mass).max()
+    A = _helmholtz_oracle(pr)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=81)
+    d = op.initialize_dof_vector()
+    d.fill_(float("nan"))
+    op.vmult(d, dev(s))
+    assert rel(d.cpu().numpy(), A(s)) < TOL_OP
+    acc = torch.full_like(d, 0.25)
+    mf.cell_loop(op.coef, dev(s), acc)
+    assert rel(acc.cpu().numpy() - 0.25, O.apply_helmholtz_cells(pr.mesh, pr.N, pr.D, pr.w, s)) < TOL_OP
+    b = op.assemble_rhs()
+    its = 6
+    xr, _, _ = O.cg_plain(A, pr.rhs(), its)
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(its, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == its and "8388608" in ctl.apply_kernel and rel(x.cpu().numpy(), xr) < TOL_CG
+    with pytest.raises(pkg.BP5Error):
+        mf.set_apply_variant(10)                          # pencil kernel (0) and block kernel (56) only
+    with pytest.raises(pkg.BP5Error):
+        op.compute_diagonal()                             # (Poisson operator only)
+
+
+@pytest.mark.parametrize("p,cells,block", [(1, (17, 9, 10), (8, 8, 8)), (2, (9, 8, 5), (8, 8, 4)), (3, (9, 5, 6), (8, 4, 4)), (4, (9, 8, 6), (4, 4, 4)), (4, (6, 5, 5), (4, 4, 2)),
+                                           (5, (7, 5, 3), (6, 4, 2)), (6, (5, 4, 3), (4, 4, 2)), (7, (5, 3, 3), (4, 2, 2)), (8, (3, 3, 3), (2, 2, 2))])
+@pytest.mark.parametrize("quad", [0, 1])
+def test_native_helmholtz_operator_block_kernel(p, cells, block, quad):
+    """The same operator on the deterministic block kernel (variant 56: bricks, packed indices, run-length write-out), with the CG dot
+    products fused into it: p.(A p) is the quadrature-point energy ghat^T S ghat + a JxW u_q^2, taken from registers."""
+    torch = _t()
+    pr = O.Problem(p, cells, quad, h=0.2, deform_amp=0.03)
+    mesh = pkg.BrickMesh(p, cells, h=0.2, deform_amp=0.03, cell_block=block, dof_numbering=1, cell_block_order=1)
+    perm = mesh.global_ids.astype(np.int64)
+    op = pkg.HelmholtzOperator(mesh, quad, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)
+    mf.set_block_workgroups(8)
+    A = _helmholtz_oracle(pr)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=82)
+    ref = A(s)[perm]
+    outs = []
+    for _ in range(3):
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        op.vmult(d, dev(s[perm]))
+        outs.append(d)
+    assert rel(outs[0].cpu().numpy(), ref) < TOL_OP
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    b = op.assemble_rhs()
+    its = 8
+    xr, _, _ = O.cg_plain(A, pr.rhs(), its)
+    sols = []
+    for fused in (True, False, True):
+        mf.set_cg_fusion(fused)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(its, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.dot_products_fused == fused and ctl.apply_kernel.startswith(f"apply_block_kernel<{p},")
+        assert rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+        sols.append(x)
+    assert torch.equal(sols[0], sols[2])
+    x = op.initialize_dof_vector()
+    ctl = pkg.IterationNumberControl(its, 0.0)
+    pkg.SolverCG(ctl).solve(op, x, b, pkg.DiagonalMatrix())          # standard CG: d.h from the kernel's energy
+    assert ctl.dot_products_fused and rel(x.cpu().numpy(), xr[perm]) < TOL_CG
+
+
+def test_native_helmholtz_reproduces_the_step64_tutorial_norms():
+    """HelmholtzProblem::run of step-64 (step-64/step-64.cu:602-616,619-650): FE_Q(3), unit cube, -Laplace u + a u = 1, zero Dirichlet values,
+    CG to 1e-12 |b|: the tutorial prints `solution norm` 0.0205439 / 0.0205269 for 343 / 2197 DoFs (remembered output of the upstream
+    tutorial, SURVEY 8c: a sanity signal, the oracle reproduces the same digits).  Here through the library's NATIVE Helmholtz kernel."""
+    for n, want in ((2, 0.0205439), (4, 0.0205269)):
+        mesh = pkg.BrickMesh(3, (n, n, n), h=1.0 / n)
+        op = pkg.HelmholtzOperator(mesh, pkg.QUAD_GAUSS, pkg.COEF_STEP64)
+        b = op.assemble_rhs()
+        x = op.initialize_dof_vector()
+        ctl = pkg.SolverControl(1000, 1e-12 * float(_t().linalg.norm(b)))
+        pkg.SolverCG(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert abs(op.l2_norm_solution(x) - want) < 6e-8, (n, op.l2_norm_solution(x))
+
+
+def test_native_helmholtz_behind_the_halo_exchange():
+    """The Helmholtz build inside the distributed entry points: a slab mesh with a ghost plane exchanged with itself through RCCL (as
+    test_block_kernel_behind_the_halo_exchange), block kernel with fused dot products in every exchange schedule: the same bits."""
+    from types import SimpleNamespace
+    torch = _t()
+    p, cells = 4, (9, 8, 10)
+    m1 = pkg.BrickMesh(p, cells, deform_amp=0.03, rank=1, n_ranks=2, cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1)
+    ng, no = m1.n_ghost, m1.n_owned
+    mesh = SimpleNamespace(degree=p, n=p + 1, cells=cells, n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
+                           n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
+                           cell_block_offsets=m1.cell_block_offsets, rank=0, n_ranks=1, h=1.0, deform_amp=0.03, n_neighbors=1,
+                           neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32), send_indices=_consistent_self_glue(m1),
+                           recv_offsets=np.asarray([0, ng], np.uint32))
+    comm = pkg.Communicator(0, 1)
+    op = pkg.HelmholtzOperator(mesh, 0, pkg.COEF_STEP64, comm=comm)
+    op.mf_data.set_apply_variant(56)
+    op.mf_data.set_block_workgroups(8)
+    b = op.assemble_rhs()
+    xs = []
+    for overlap, sched in ((0, 1), (1, 2), (2, 4)):
+        op.mf_data.set_overlap(overlap)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(10, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.dot_products_fused and ctl.exchange_schedule == sched and "9725952" in ctl.apply_kernel
+        xs.append(x)
+    assert torch.equal(xs[0], xs[1]) and torch.equal(xs[0], xs[2])
+    op.mf_data.set_cg_fusion(False)
+    op.mf_data.set_overlap(0)
+    x = op.initialize_dof_vector()
+    pkg.SolverCGFullMerge(pkg.IterationNumberControl(10, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+    assert float((x - xs[0]).abs().max()) < 1e-11 * float(x.abs().max())
+    op.mf_data.synchronize()
+    op.mf_data.close()
+    comm.close()
+
 
 # ------------------------------------------------------------------ hanging nodes (SURVEY 8 f4)
 def _hanging_namespace(m):
