@@ -125,7 +125,6 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
           }
         }
       BP5_TRY(upload(&mf->d_hang_I, I.data(), I.size()));
-      mf->apply_variant = 90;
     }
   }
   // halo plan
@@ -239,9 +238,9 @@ static bool product_variant(int degree, int v)
 extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
 {
   if (!mf) return fail(BP5_ERR_INVALID, "null handle");
-  if (mf->has_hanging) {
-    if (v != 0 && v != 90) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variant 90 only");
-    mf->apply_variant = 90;
+  if (mf->has_hanging) { // 0: the library decides; 56: block kernel (deterministic; needs cell blocks); 90: pencil kernel with atomics (any mesh)
+    if (v != 0 && v != 90 && !(v == 56 && block_lpc(mf->degree) != 0)) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variants 90 (pencil kernel) and 56 (block kernel)");
+    mf->apply_variant = v;
     return BP5_OK;
   }
   if (v == 90) return fail(BP5_ERR_INVALID, "apply variant 90 is the hanging-node kernel: the mesh has no constraint masks");
@@ -622,12 +621,13 @@ bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uin
 // bitwise reproducible), whole cell range only; p = 4 affine geometry: team kernel; everything else: pencil kernel.
 static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 {
-  if (mf->has_hanging) return 90;
   const int v = mf->apply_variant;
   if (v != 0) return v;
-  if (mf->operator_kind == BP5_OP_HELMHOLTZ) { // pencil kernel, or the block kernel under the same conditions as below
+  if (mf->has_hanging && mf->geometry_mode == BP5_GEOM_AFFINE) return 90;
+  if (mf->operator_kind == BP5_OP_HELMHOLTZ || mf->has_hanging) { // pencil kernel, or the block kernel under the same conditions as below
+    const int pencil = mf->has_hanging ? 90 : 0;
     uint32_t hb0, hb1;
-    if (!block_lpc(mf->degree) || mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &hb0, &hb1)) return 0;
+    if (!block_lpc(mf->degree) || mf->h_block_off.empty() || !block_aligned(mf, c0, c1, &hb0, &hb1)) return pencil;
     if (mf->auto_block < 0) {
       bp5_mf::DevPlan *dp = nullptr;
       mf->auto_block = 0;
@@ -641,8 +641,8 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
         mf->auto_block = lds * 2 <= 160 * 1024 && dp->n_groups >= 2u * (uint32_t)std::max(mf->n_cus, 1);
       }
     }
-    if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (hb1 - hb0) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return 0;
-    return mf->auto_block ? 56 : 0;
+    if (mf->auto_block && (c0 != 0 || c1 != mf->n_cells) && (hb1 - hb0) < 30u * (uint32_t)std::max(mf->n_cus, 1)) return pencil;
+    return mf->auto_block ? 56 : pencil;
   }
   if ((mf->degree == 1 || mf->degree == 3) && mf->h_block_off.empty()) {
     if (mf->geometry_mode == BP5_GEOM_AFFINE) return 0;
@@ -782,8 +782,9 @@ static int launch_diagonal(bp5_mf *mf, const double *coef, double *diag)
                      mf->has_hanging ? (const uint32_t *)mf->d_hang_mask : (const uint32_t *)nullptr);
   KERNEL_CHECK();
   if (mf->has_hanging) { // the coarse DoFs named on constrained faces / edges: one cell-operator application per such entry
-    hipLaunchKernelGGL(diagonal_hanging_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, coef, mf->coef_plane_stride, mf->coef_cell_stride, mf->d_tab,
-                       mf->n_cells, diag, (const uint32_t *)mf->d_hang_mask, (const double *)mf->d_hang_I);
+    hipLaunchKernelGGL(diagonal_hanging_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, affine ? mf->d_scalar_plane : coef,
+                       affine ? (uint64_t)mf->n_cells * mf->n3 : mf->coef_plane_stride, affine ? (uint64_t)mf->n3 : mf->coef_cell_stride, affine ? mf->d_gcell : (const double *)nullptr,
+                       mf->d_tab, mf->n_cells, diag, (const uint32_t *)mf->d_hang_mask, (const double *)mf->d_hang_I);
     KERNEL_CHECK();
   }
   return BP5_OK;
@@ -793,7 +794,6 @@ extern "C" int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag
 {
   if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !diag) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(mf->device));
-  if (mf->has_hanging && mf->geometry_mode == BP5_GEOM_AFFINE) return fail(BP5_ERR_UNSUPPORTED, "bp5_compute_diagonal on meshes with hanging nodes in the affine geometry mode");
   if (mf->operator_kind == BP5_OP_HELMHOLTZ) return fail(BP5_ERR_UNSUPPORTED, "bp5_compute_diagonal: Poisson operator only");
   HIP_TRY(hipMemsetAsync(diag, 0, mf->n_local() * sizeof(double), mf->stream));
   if (mf->n_cells) BP5_TRY(diagonal_dispatch(mf, coef, diag));

@@ -279,7 +279,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
     mf->n_cus = prop.multiProcessorCount;
   }
-  const int wg_per_cu = ((ABL & 2048) && !(ABL & 8388608) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (the Helmholtz build: two per CU, registers)
+  const int wg_per_cu = ((ABL & 2048) && !(ABL & (8388608 | 2097152)) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (Helmholtz / hanging-node builds: two per CU, registers)
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
@@ -339,6 +339,8 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   a.plane_stride = mf->coef_plane_stride; a.cell_stride = (ABL & 1024) ? (uint64_t)mf->n3 : mf->coef_cell_stride; // (affine builds read ONE scalar plane)
   a.cell_begin = 0; a.cell_end = mf->n_cells; a.n_teams = dp->n_groups; a.teams_per_xcd = 0;
   a.gcell = mf->d_gcell; a.n_cells_total = mf->n_cells;
+  a.hang_mask = mf->d_hang_mask; a.hang_I = mf->d_hang_I;
+  if ((ABL & 2097152) && !mf->has_hanging) return fail(BP5_ERR_INVALID, "the hanging-node build needs constraint masks");
   ShapeArg<n> sh;
   fill_shape(sh, mf);
   const bool set = overwrite && dp->covers_all;
@@ -532,14 +534,35 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
                  : launch_apply_t<DEG, false, TWE, n2e, TPBE, true, HELM>(mf, coef, src, dst, c0, c1);
   }
   if (mf->has_hanging) {
-    // 2:1 refined meshes: the degree's default pencil shape with the hanging-node fix-up after the gather and its adjoint
-    // before the (atomic) scatter -- variant 90, the only operator kernel that honours constraint masks
-    if (mf->apply_variant != 90) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variant 90 only");
-    if (mf->geometry_mode == BP5_GEOM_AFFINE) return fail(BP5_ERR_UNSUPPORTED, "hanging nodes with the affine geometry mode");
+    // 2:1 refined meshes (resolve_hanging_nodes, bp5/fe_evaluation_gl.h:150-151,167-168): the hanging-node fix-up after the gather and its
+    // adjoint before the scatter.  Variant 56: the deterministic block kernel (cell blocks, packed indices; the CG dot products fused when
+    // the solver asks); variant 90: the degree's default pencil shape with atomics (any mesh; also the affine geometry mode)
+    if (mf->apply_variant == 56 && mf->geometry_mode != BP5_GEOM_AFFINE) {
+      if constexpr (block_lpc(DEG) != 0) {
+        constexpr int LPCB = block_lpc(DEG);
+        constexpr int HANG = 2097152;
+        const bool coll_ = mf->quadrature == BP5_QUAD_GLL;
+        if (c1 <= c0) { if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream)); return BP5_OK; }
+        if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "variant 56 needs a cell range aligned with the cell blocks");
+        struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+        bp5_mf::DevPlan *dp_ = nullptr;
+        BP5_TRY(get_plan_raw(mf, -(256 / LPCB), &dp_));
+        if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 56 needs packed indices (<= 128 runs per cell block)");
+        if (mf->fuse.on)
+          return coll_ ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HANG>(mf, coef, src, dst, overwrite)
+                       : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HANG>(mf, coef, src, dst, overwrite);
+        return coll_ ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + HANG>(mf, coef, src, dst, overwrite)
+                     : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + HANG>(mf, coef, src, dst, overwrite);
+      }
+    }
+    if (mf->apply_variant != 90) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variants 90 (pencil kernel) and 56 (block kernel)");
     if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     if (c1 <= c0) return BP5_OK;
     constexpr int n2h = (DEG + 1) * (DEG + 1);
     constexpr int TWH = DEG <= 3 ? 1 : 4, TPBH = DEG <= 3 ? 4 : 1;
+    if (mf->geometry_mode == BP5_GEOM_AFFINE) // all cells affine (undeformed 2:1 meshes): per-cell K K^T + one scalar plane
+      return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<DEG, true, TWH, n2h, TPBH, true, 2097152 + 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1)
+                                            : launch_apply_t<DEG, false, TWH, n2h, TPBH, true, 2097152 + 1024>(mf, mf->d_scalar_plane, src, dst, c0, c1);
     return mf->quadrature == BP5_QUAD_GLL ? launch_apply_t<DEG, true, TWH, n2h, TPBH, true, 2097152>(mf, coef, src, dst, c0, c1)
                                           : launch_apply_t<DEG, false, TWH, n2h, TPBH, true, 2097152>(mf, coef, src, dst, c0, c1);
   }

@@ -1208,6 +1208,7 @@ struct PassRegs {
   double Gc[AFFINE ? 6 : 1];   // ... and the cell's constant K K^T
   uint32_t idx[n];
   uint32_t ent; // pass_cell entry
+  uint32_t mask; // hanging-node builds: the cell's constraint mask (BP5_HANG_*)
   int round;
   bool active;
 };
@@ -1242,6 +1243,11 @@ struct BlockPass {
   static constexpr bool HELM = (ABL & 8388608) != 0;
   static constexpr int NPL = HELM ? 7 : 6;
   static_assert(!HELM || (!AFFINE && (ABL & 8192) != 0), "Helmholtz build: six-plane geometry, sequential tiles");
+  // HANG: 2:1 refined meshes -- resolve_hanging_nodes after the gather and its adjoint before the accumulation into the brick vector
+  // (bp5/fe_evaluation_gl.h:150-151,167-168), through the cell's transpose tile like apply_pencil_kernel; a pass without a flagged
+  // cell skips both (one ballot / one barrier-with-or per pass)
+  static constexpr bool HANG = (ABL & 2097152) != 0;
+  static_assert(!HANG || (ABL & 8192) != 0, "hanging-node build: sequential tiles");
   using R = PassRegs<n, AFFINE, NPL>;
   // all lanes of a cell slot sit in one wave when LPC divides 64: the tile exchanges then need no block barrier
   static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
@@ -1273,6 +1279,7 @@ struct BlockPass {
       load_pencil_idx<n, uint16_t>(bp.pos + cell * n3, abm, r.ps);
     }
     r.round = bp.cell_round[cell];
+    if constexpr (HANG) r.mask = a.hang_mask[cell];
     if constexpr (!SINGLE) issue_metric(a, r, abm);
   }
   static __device__ __forceinline__ void issue_metric(const ApplyArgs &a, R &r, int abm)
@@ -1326,6 +1333,13 @@ struct BlockPass {
 #define T1(k, j, i) T[(k) * L::PS + (j) * L::RS + (i)]
       const bool act = cur.active;
       double(&uu)[n] = cur.u;
+      bool hang_any = false;
+      if constexpr (HANG) {
+        const bool flagged = act && (cur.mask & BP5_HANG_ANY) != 0;
+        if constexpr (WAVE_LOCAL) hang_any = __builtin_amdgcn_ballot_w64(flagged) != 0ull; // the cells of a wave exchange through their own tiles
+        else hang_any = __syncthreads_or(flagged) != 0;
+        if (hang_any) pencil_hang_resolve<n, WAVE_LOCAL ? 1 : 4, false, L>(cur.mask, a.hang_I, uu, T, a_, b_, act);
+      }
       double q0[n], q1[n], q2[n];
       double um[HELM ? n : 1]; // HELM: u at this lane's quadrature points, then a JxW u
       if constexpr (!COLL) {
@@ -1538,6 +1552,7 @@ struct BlockPass {
         tile_sync();
         MV_DT_ADD(sh.D, z2, yy);
       }
+      if constexpr (HANG) { if (hang_any) pencil_hang_resolve<n, WAVE_LOCAL ? 1 : 4, true, L>(cur.mask, a.hang_I, yy, T, a_, b_, act); } // adjoint
       BP5_STAMP(4)
       for (int rd = 0; rd < n_rounds; ++rd) {
         lds_drain(); // see lds_drain(): the barrier is a loop header
@@ -1717,7 +1732,7 @@ struct BlockPass {
 };
 
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 8388608)) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & (8388608 | 2097152))) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;
@@ -2368,7 +2383,7 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
 // interpolation -- R e_s is not a tensor product in general (a DoF on the edge shared by two constrained faces spreads into
 // both), so each such entry takes one application of the cell operator to R e_s.  Setup-time kernel, flagged cells only.
 template <int n>
-__global__ void __launch_bounds__(n *n *n) diagonal_hanging_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, uint64_t cell_stride,
+__global__ void __launch_bounds__(n *n *n) diagonal_hanging_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, uint64_t cell_stride, const double *gcell,
                                                                   const double *tab, uint32_t n_cells, double *diag, const uint32_t *hang_mask,
                                                                   const double *hang_I)
 {
@@ -2383,7 +2398,7 @@ __global__ void __launch_bounds__(n *n *n) diagonal_hanging_kernel(const uint32_
     double S[6];
     const uint64_t at = cell * cell_stride + coef_off<n>(i, j + n * k);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) S[c] = coef[(uint64_t)c * plane_stride + at];
+    for (int c = 0; c < 6; ++c) S[c] = gcell ? coef[at] * gcell[(uint64_t)c * n_cells + cell] : coef[(uint64_t)c * plane_stride + at]; // (affine mode: scalar plane x the cell's K K^T)
     for (int s = 0; s < n3; ++s) {
       const int si = s % n, sj = (s / n) % n, sk = s / n2;
       if (!(hang_on_line(hm, 0, si, sj, sk, n - 1) || hang_on_line(hm, 1, si, sj, sk, n - 1) || hang_on_line(hm, 2, si, sj, sk, n - 1))) continue; // block-uniform

@@ -450,6 +450,133 @@ class RefinedBrickMesh:
         return resolve_hanging(self, X)
 
 
+class OctreeBrickMesh:
+    """2:1 balanced mesh with ANY number of refinement levels: a brick of Nx x Ny x Nz cubes of side H (level 0); `refine[l]` is a bool array
+    on the level-l grid ([z][y][x], 2^l Nz x 2^l Ny x 2^l Nx) flagging the level-l cubes that are split into 8 (a flag only counts where the
+    cube exists, i.e. where its parent was split).  Same per-cell description as RefinedBrickMesh (which it reproduces for one level): a leaf
+    whose neighbour across a face / edge is a leaf ONE level coarser carries HANG_FACE / HANG_EDGE bits and names the coarse entity's DoFs.
+    What the per-cell masks cannot express is refused here: a level difference of more than one across a face or edge (2:1 balance), and
+    chained constraints (a coarse entity whose own DoFs hang on a still coarser cell) -- refined regions of successive levels must keep one
+    unconstrained cell between their rims.  Cells: level by level; level 0 x fastest, finer levels parent by parent (the children of one
+    cube are consecutive: compact 2 x 2 x 2 groups).  Zero Dirichlet on the whole boundary."""
+
+    def __init__(self, p, coarse, refine, H=1.0, deform_amp=0.0):
+        self.p, self.n = p, p + 1
+        n, last = self.n, p
+        nodes, _ = gll_01(n)
+        Nx, Ny, Nz = coarse
+        self.L = (Nx * H, Ny * H, Nz * H)
+        n_levels = len(refine) + 1
+        split = []                                              # split[l][(x, y, z)]: the level-l cube exists and is refined
+        exists = [{(x, y, z) for z in range(Nz) for y in range(Ny) for x in range(Nx)}]
+        for l, r in enumerate(refine):
+            r = np.asarray(r, bool).reshape(2 ** l * Nz, 2 ** l * Ny, 2 ** l * Nx)
+            sp = {c for c in exists[l] if r[c[2], c[1], c[0]]}
+            split.append(sp)
+            exists.append({(2 * c[0] + dx, 2 * c[1] + dy, 2 * c[2] + dz) for c in sp for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)})
+        split.append(set())
+        leaf = lambda l, c: 0 <= l < n_levels and c in exists[l] and c not in split[l]
+        fine = lambda l, c: 0 <= l < n_levels and c in split[l]
+        keys, coords = {}, []
+        ax = np.arange(n)
+        coord = [ax[None, None, :], ax[None, :, None], ax[:, None, None]]
+        unit = np.eye(3, dtype=int)
+
+        def own_nodes(l, c):
+            h = H / 2 ** l
+            return np.stack(np.meshgrid(c[2] * h + h * nodes, c[1] * h + h * nodes, c[0] * h + h * nodes, indexing="ij")[::-1], -1)
+
+        def key(x):
+            return tuple(np.round(x / H * 2 ** 30).astype(np.int64))
+
+        # pass 1: masks and the entries that name a coarser leaf's DoFs (by (level, cube, local index) until those are numbered)
+        leaves = []
+        for l in range(n_levels):
+            for c in sorted(exists[l] - split[l], key=lambda c: (c[2], c[1], c[0]) if l == 0 else (c[2] // 2, c[1] // 2, c[0] // 2, c[2], c[1], c[0])):
+                msk, src = 0, {}
+                if l > 0:
+                    P = np.array([c[0] // 2, c[1] // 2, c[2] // 2])
+                    ch = [c[0] % 2, c[1] % 2, c[2] % 2]
+                    sgn = [1 if ch[e] else -1 for e in range(3)]
+                    for e in range(3):
+                        Q = tuple(P + sgn[e] * unit[e])
+                        if leaf(l - 1, Q):
+                            msk |= HANG_FACE[e]
+                            sel = np.broadcast_to(coord[e] == ch[e] * last, (n, n, n))
+                            opp = np.broadcast_to(coord[e] == (1 - ch[e]) * last, (n, n, n))
+                            for a, b in zip(np.argwhere(sel), np.argwhere(opp)):
+                                src[tuple(a)] = (l - 1, Q, tuple(b))
+                        elif not fine(l - 1, Q) and all(0 <= Q[k] < 2 ** (l - 1) * coarse[k] for k in range(3)):
+                            raise ValueError("not 2:1 balanced across a face")
+                    for d in range(3):
+                        e1, e2 = [e for e in range(3) if e != d]
+                        Q1, Q2 = tuple(P + sgn[e1] * unit[e1]), tuple(P + sgn[e2] * unit[e2])
+                        Qd = tuple(P + sgn[e1] * unit[e1] + sgn[e2] * unit[e2])
+                        if leaf(l - 1, Qd) and fine(l - 1, Q1) and fine(l - 1, Q2):
+                            msk |= HANG_EDGE[d]
+                            sel = np.broadcast_to((coord[e1] == ch[e1] * last) & (coord[e2] == ch[e2] * last), (n, n, n))
+                            opp = np.broadcast_to((coord[e1] == (1 - ch[e1]) * last) & (coord[e2] == (1 - ch[e2]) * last), (n, n, n))
+                            for a, b in zip(np.argwhere(sel), np.argwhere(opp)):
+                                src[tuple(a)] = (l - 1, Qd, tuple(b))
+                    if msk:
+                        for e in range(3):
+                            if ch[e]:
+                                msk |= HANG_SIDE[e] | HANG_HALF[e]
+                leaves.append((l, c, msk, src))
+        # pass 2: number the DoFs level by level (a coarse leaf's entries exist before a finer leaf names them)
+        ids_of, cells, masks = {}, [], []
+        for l, c, msk, src in leaves:
+            X = own_nodes(l, c)
+            ids = np.empty((n, n, n), np.int64)
+            for idx in np.ndindex(n, n, n):
+                if idx in src:
+                    continue
+                k = key(X[idx])
+                if k not in keys:
+                    keys[k] = len(coords)
+                    coords.append(X[idx])
+                ids[idx] = keys[k]
+            for idx, (lq, Q, j) in src.items():
+                srcs = [lv for lv in leaves if lv[0] == lq and lv[1] == Q][0][3]
+                if j in srcs:
+                    raise ValueError("chained constraint: the coarse entity's DoFs hang on a still coarser cell")
+                ids[idx] = ids_of[(lq, Q)][j]
+            ids_of[(l, c)] = ids
+            cells.append(ids.ravel())
+            masks.append(msk)
+        # audit: a node that keeps its own DoF must not lie on a COARSER leaf unless it is one of that leaf's nodes
+        own = {(l, c): set(map(int, ids_of[(l, c)].ravel())) for l, c, _, _ in leaves}
+        for l, c, msk, src in leaves:
+            X, ids = own_nodes(l, c), ids_of[(l, c)]
+            for idx in np.ndindex(n, n, n):
+                if idx in src:
+                    continue
+                for (lq, Q), dofs in own.items():
+                    if lq >= l:
+                        continue
+                    hq = H / 2 ** lq
+                    if all(Q[e] * hq - 1e-12 <= X[idx][e] <= (Q[e] + 1) * hq + 1e-12 for e in range(3)):
+                        assert int(ids[idx]) in dofs, "hanging node without a constraint"
+        self.levels = np.asarray([l for l, _, _, _ in leaves])
+        self.l2g = np.asarray(cells, dtype=np.uint32)
+        self.constraint_mask = np.asarray(masks, dtype=np.uint32)
+        self.n_cells = self.l2g.shape[0]
+        self.n_coarse_cells = int((self.levels == 0).sum())
+        self.n_dofs = len(coords)
+        c0 = np.asarray(coords)
+        eps = 1e-12
+        bnd = np.zeros(self.n_dofs, bool)
+        for e in range(3):
+            bnd |= (c0[:, e] < eps) | (c0[:, e] > self.L[e] - eps)
+        self.constrained = np.nonzero(bnd)[0].astype(np.uint32)
+        self.coords = deform_sine(c0, self.L, deform_amp) if deform_amp != 0.0 else c0
+
+    def cell_node_coords(self):
+        n = self.n
+        X = self.coords[self.l2g.astype(np.int64)].reshape(self.n_cells, n, n, n, 3).copy()
+        return resolve_hanging(self, X)
+
+
 # ----------------------------------------------------------------------------- geometry (A.3)
 def _grad_ref(u, N, D):
     """u: [..., k, j, i] nodal values -> (g0,g1,g2) reference gradients at q-points [..., qk, qj, qi].

@@ -1562,6 +1562,148 @@ def test_hanging_nodes_on_general_two_level_meshes(pattern, p, quad, amp):
     assert rel(x.cpu().numpy(), xj) < TOL_CG
 
 
+def _with_cell_blocks(m, group):
+    """The mesh handed over the way a host that cares for the block kernel does it: cells in groups of `group` consecutive cells, DoFs
+    renumbered block-major -- all DoFs touched by the same SET of cell groups consecutively (the brick-major numbering of the library's own
+    mesh generator, for an arbitrary mesh): a group's DoF list is then a few dozen runs (the oracle numbers by first appearance: a run per line
+    of a shared face).  Returns the mesh namespace and new_of_old (vectors: new[new_of_old] = old)."""
+    # unrefined cubes in groups of `group` consecutive cells, refined ones parent by parent (the generators emit the children of one cube
+    # consecutively: compact 2 x 2 x 2 groups)
+    levels = getattr(m, "levels", None)
+    starts = [0, m.n_coarse_cells] if levels is None else [int(np.argmax(levels == lv)) for lv in sorted(set(levels))]
+    starts.append(m.n_cells)
+    offsets = []
+    for k in range(len(starts) - 1):
+        offsets += list(range(starts[k], starts[k + 1], group if k == 0 else 8))
+    offsets = np.asarray(offsets + [m.n_cells], np.uint32)
+    l2g = m.l2g.astype(np.int64)
+    sig = [set() for _ in range(m.n_dofs)]
+    for b in range(len(offsets) - 1):
+        for g in np.unique(l2g[offsets[b]:offsets[b + 1]]):
+            sig[g].add(b)
+    con = np.zeros(m.n_dofs, bool)
+    con[m.constrained.astype(np.int64)] = True          # (Dirichlet DoFs apart: the run tables carry the flag per run)
+    order = sorted(range(m.n_dofs), key=lambda g: (min(sig[g]) if sig[g] else 1 << 30, tuple(sorted(sig[g])), bool(con[g]), g))
+    new_of_old = np.empty(m.n_dofs, np.int64)
+    new_of_old[np.asarray(order)] = np.arange(m.n_dofs)
+    ns = _hanging_namespace(m)
+    ns.l2g = new_of_old[l2g].astype(np.uint32)
+    ns.coords = m.coords[np.asarray(order)]
+    ns.constrained = np.sort(new_of_old[m.constrained.astype(np.int64)]).astype(np.uint32)
+    ns.cell_block_offsets = offsets
+    return ns, new_of_old
+
+
+def _three_level(p, amp):
+    r0 = np.zeros((3, 3, 4), bool)
+    r0[:, :, :2] = True
+    r1 = np.zeros((6, 6, 8), bool)
+    r1[:2, :2, :2] = True
+    return O.OctreeBrickMesh(p, (4, 3, 3), [r0, r1], H=0.5, deform_amp=amp)
+
+
+@pytest.mark.parametrize("mesh_kind,p,quad,amp,group", [("stairs", 1, 0, 0.0, 3), ("stairs", 2, 0, 0.03, 3), ("L", 3, 1, 0.0, 2), ("L", 4, 0, 0.02, 2), ("core", 2, 1, 0.0, 3),
+                                                        ("stairs", 5, 0, 0.0, 3), ("L", 6, 0, 0.02, 2), ("L", 7, 1, 0.0, 2), ("L", 8, 0, 0.02, 1),
+                                                        ("three", 2, 0, 0.0, 4), ("three", 3, 0, 0.03, 4), ("three", 4, 0, 0.0, 2)])
+def test_hanging_nodes_in_the_deterministic_block_kernel(mesh_kind, p, quad, amp, group):
+    """resolve_hanging_nodes inside the block kernel (bp5/fe_evaluation_gl.h:150-151,167-168; round 2 ran refined meshes on the atomic pencil
+    kernel only): fix-up after the packed gather, adjoint before the accumulation into the brick vector, only in passes that hold a flagged
+    cell.  Cells handed over in groups of consecutive cells (neighbours share DoFs: multi-round passes), every degree; two-level meshes
+    (faces in every number, constrained edges) and a THREE-level octree mesh.  Against the oracle and the pencil kernel; bitwise
+    reproducible; merged CG with the dot products fused into it (the energy is taken from the resolved values); Jacobi preconditioner."""
+    torch = _t()
+    m = _three_level(p, amp) if mesh_kind == "three" else _refined(mesh_kind, p, amp)
+    if mesh_kind == "three":
+        assert set(m.levels) == {0, 1, 2}
+    _, _, w, N, D = O.shape_tables(p, quad)
+    coef_ref = O.merged_metric(m, N, D, w, O.kappa_step64)
+    c = m.constrained.astype(np.int64)
+
+    def A(s):
+        d = O.apply_cells(m, coef_ref, N, D, s)
+        d[c] = s[c]
+        return d
+
+    ns, new_of_old = _with_cell_blocks(m, group)
+    to_new = lambda v: dev(v[np.argsort(new_of_old)])      # oracle order -> the renumbered mesh
+    to_old = lambda t: t.cpu().numpy()[new_of_old]
+    op = pkg.PoissonOperator(ns, quad, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)
+    mf.set_block_workgroups(8)
+    assert mf.block_plan_info()[2], mf.block_plan_info()   # packed indices available
+    s = O.deterministic_src(m.n_dofs, seed=73)
+    outs = []
+    for _ in range(3):
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        op.vmult(d, to_new(s))
+        outs.append(d)
+    assert rel(to_old(outs[0]), A(s)) < TOL_OP
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    mf.set_apply_variant(90)                                # the atomic pencil kernel on the same handle
+    d90 = op.initialize_dof_vector()
+    op.vmult(d90, to_new(s))
+    assert float((d90 - outs[0]).abs().max()) < 1e-12 * float(d90.abs().max())
+    mf.set_apply_variant(56)
+    b = op.assemble_rhs()
+    b_ref = O.assemble_rhs(m)
+    assert rel(to_old(b), b_ref) < TOL_OP
+    its = 3 if p == 1 else 6
+    xr, _, _ = O.cg_plain(A, b_ref, its)
+    sols = []
+    for fused in (True, False, True):
+        mf.set_cg_fusion(fused)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(its, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.dot_products_fused == fused and ctl.apply_kernel.startswith(f"apply_block_kernel<{p},")
+        assert int(ctl.apply_kernel.split(",")[-1].rstrip(">")) & 2097152
+        assert rel(to_old(x), xr) < TOL_CG
+        sols.append(x)
+    assert torch.equal(sols[0], sols[2])
+    x = op.initialize_dof_vector()
+    pkg.SolverCG(pkg.IterationNumberControl(its, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+    assert rel(to_old(x), xr) < TOL_CG
+    d_ref = O.operator_diagonal(m, coef_ref, N, D)
+    assert rel(to_old(op.compute_diagonal()), d_ref) < 1e-13
+    assert abs(op.l2_norm_solution(x) - O.l2_norm_solution(m, xr)) < 1e-11 * O.l2_norm_solution(m, xr)
+
+
+@pytest.mark.parametrize("mesh_kind,p,quad", [("stairs", 2, 0), ("L", 3, 1), ("three", 2, 0), ("L", 5, 0)])
+def test_hanging_nodes_in_the_affine_geometry_mode(mesh_kind, p, quad):
+    """Undeformed 2:1 meshes are affine cell by cell: BP5_GEOM_AFFINE (per-cell K K^T + one scalar plane, G = 1) with hanging nodes -- operator
+    (pencil kernel: affine build + hanging-node fix-up), solvers and the Jacobi diagonal (round 2 refused the diagonal in this mode)."""
+    m = _three_level(p, 0.0) if mesh_kind == "three" else _refined(mesh_kind, p, 0.0)
+    _, _, w, N, D = O.shape_tables(p, quad)
+    coef_ref = O.merged_metric(m, N, D, w, O.kappa_step64)
+    c = m.constrained.astype(np.int64)
+
+    def A(s):
+        d = O.apply_cells(m, coef_ref, N, D, s)
+        d[c] = s[c]
+        return d
+
+    op = pkg.PoissonOperator(_hanging_namespace(m), quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE)
+    assert op.coef is None and op.mf_data.get_apply_variant() == 90
+    s = O.deterministic_src(m.n_dofs, seed=74)
+    d = op.initialize_dof_vector()
+    d.fill_(float("nan"))
+    op.vmult(d, dev(s))
+    assert rel(d.cpu().numpy(), A(s)) < TOL_OP
+    d_ref = O.operator_diagonal(m, coef_ref, N, D)
+    assert rel(op.compute_diagonal().cpu().numpy(), d_ref) < 1e-13
+    b = op.assemble_rhs()
+    its = 6
+    xj, _, _ = O.cg_merged(A, O.assemble_rhs(m), its, diag=1.0 / d_ref)
+    x = op.initialize_dof_vector()
+    pkg.SolverCGFullMerge(pkg.IterationNumberControl(its, 0.0)).solve(op, x, b, pkg.DiagonalMatrix(op.compute_diagonal(invert=True)))
+    assert rel(x.cpu().numpy(), xj) < TOL_CG
+    with pytest.raises(pkg.BP5Error):
+        op.mf_data.set_apply_variant(56)                  # (accepted as a request, refused at the launch: the affine block build has no hanging-node path)
+        op.vmult(d, dev(s))
+
+
 def test_hanging_node_golden_fixtures():
     """the committed outputs of tests/golden/hanging_cases.npz (operator, RHS, diagonal, 6 CG iterations on a staircase-refined mesh)
     straight against the HIP path, without the oracle in between"""

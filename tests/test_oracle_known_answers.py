@@ -373,6 +373,89 @@ def test_hanging_nodes_on_general_two_level_meshes(pattern, p, amp):
     assert abs(O.assemble_rhs(m).sum() - vol) < 1e-12 * vol
 
 
+def _three_level_mesh(p, amp=0.0):
+    """4 x 3 x 3 cubes; the 2 x 3 x 3 block at low x is refined once, and of its level-1 cubes the 2 x 2 x 2 block in the low-x / low-y /
+    low-z corner once more: three levels, and one unconstrained level-1 cell between the level-2 region and the level-0 cells."""
+    r0 = np.zeros((3, 3, 4), bool)
+    r0[:, :, :2] = True
+    r1 = np.zeros((6, 6, 8), bool)
+    r1[:2, :2, :2] = True
+    return O.OctreeBrickMesh(p, (4, 3, 3), [r0, r1], H=0.5, deform_amp=amp)
+
+
+@pytest.mark.parametrize("p,amp", [(1, 0.0), (2, 0.0), (3, 0.0), (2, 0.03)])
+def test_three_level_octree_mesh(p, amp):
+    """Three refinement levels, 2:1 balanced (OctreeBrickMesh): the same known answers as for two levels -- every cell recovers its own GLL
+    nodes and a polynomial's values through the gather + fix-up (conforming across all level jumps), exact energy, null space, symmetry,
+    volume; and the generator refuses what per-cell masks cannot express (a level difference of two across a face, chained constraints)."""
+    m = _three_level_mesh(p, amp)
+    n = m.n
+    assert set(m.levels) == {0, 1, 2} and (m.constraint_mask[m.levels == 2] != 0).any() and (m.constraint_mask[m.levels == 1] != 0).any()
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    Lx, Ly, Lz = m.L
+    vol_exact = Lx * Ly * Lz
+    _, JxW, _ = O.jacobians(m, N, D, w)
+    vol = JxW.sum()
+    coef = O.merged_metric(m, N, D, w)
+    if amp == 0.0:
+        assert abs(vol - vol_exact) < 1e-13
+        f = lambda X: X[..., 0] ** p + 2.0 * X[..., 1] * X[..., 2] - 0.5 * X[..., 2] ** p * X[..., 0]
+        u = f(m.coords)
+        ul = O.resolve_hanging(m, u[m.l2g.astype(np.int64)].reshape(m.n_cells, n, n, n).copy())
+        Xc = m.cell_node_coords()
+        nodes, _ = O.gll_01(n)
+        for c in range(m.n_cells):
+            lo, h = Xc[c].reshape(-1, 3).min(0), 0.5 / 2 ** m.levels[c]
+            for e, ax in ((0, 2), (1, 1), (2, 0)):
+                line = np.moveaxis(Xc[c][..., e], ax, 0).reshape(n, -1)
+                assert np.abs(line - (lo[e] + h * nodes)[:, None]).max() < 1e-14
+        assert np.abs(ul - f(Xc)).max() < 1e-13
+        xg, wg = O.gauss_01(2 * p + 2)
+        G = np.stack(np.meshgrid(Lx * xg, Ly * xg, Lz * xg, indexing="ij"), -1)
+        W = np.einsum("i,j,k->ijk", wg, wg, wg) * vol_exact
+        x, y, z = G[..., 0], G[..., 1], G[..., 2]
+        gx = p * x ** (p - 1) - 0.5 * z ** p
+        gy = 2.0 * z
+        gz = 2.0 * y - 0.5 * p * z ** (p - 1) * x
+        exact = float(np.sum(W * (gx * gx + gy * gy + gz * gz)))
+        assert abs(u @ O.apply_cells(m, coef, N, D, u) - exact) < 1e-12 * exact
+    assert np.abs(O.apply_cells(m, coef, N, D, np.ones(m.n_dofs))).max() < 1e-12
+    rng = np.random.default_rng(5)
+    u, v = rng.standard_normal(m.n_dofs), rng.standard_normal(m.n_dofs)
+    vAu = v @ O.apply_cells(m, coef, N, D, u)
+    assert abs(vAu - u @ O.apply_cells(m, coef, N, D, v)) < 1e-11 * abs(vAu)
+    a = np.array([0.3, -1.1, 0.7])
+    ulin = m.coords @ a
+    assert abs(ulin @ O.apply_cells(m, coef, N, D, ulin) - (a @ a) * vol) < 1e-12 * (a @ a) * vol
+
+
+def test_octree_generator_reproduces_the_two_level_one_and_refuses_what_masks_cannot_express():
+    p = 2
+    coarse, r = _refine_pattern("stairs")
+    a, b = O.RefinedBrickMesh(p, coarse, r, H=0.5), O.OctreeBrickMesh(p, coarse, [r], H=0.5)
+    assert a.n_dofs == b.n_dofs and a.n_cells == b.n_cells and sorted(a.constraint_mask) == sorted(b.constraint_mask)
+    key = lambda X: [tuple(np.round(x * 2 ** 30).astype(np.int64)) for x in X]
+    pos = {k: i for i, k in enumerate(key(a.coords))}
+    perm = np.asarray([pos[k] for k in key(b.coords)])
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    ca, cb = O.merged_metric(a, N, D, w, O.kappa_step64), O.merged_metric(b, N, D, w, O.kappa_step64)
+    u = np.random.default_rng(8).standard_normal(a.n_dofs)
+    ya, yb = O.apply_cells(a, ca, N, D, u), O.apply_cells(b, cb, N, D, u[perm])
+    assert np.linalg.norm(yb - ya[perm]) < 1e-12 * np.linalg.norm(ya)
+    r0 = np.zeros((1, 1, 2), bool)
+    r0[0, 0, 0] = True
+    r1 = np.zeros((2, 2, 4), bool)
+    r1[0, 0, 1] = True                                           # a level-2 region that touches the level-0 cube: level difference 2
+    with pytest.raises(ValueError):
+        O.OctreeBrickMesh(1, (2, 1, 1), [r0, r1])
+    r0 = np.zeros((2, 1, 2), bool)
+    r0[0, 0, 0] = True                                           # cube (0,0,0) split; its +x neighbour (1,0,0) and +z neighbour (0,0,1) stay coarse
+    r1 = np.zeros((4, 2, 4), bool)
+    r1[1, 0, 0] = True                                           # child at the +z rim split again: its coarse neighbour's face hangs itself? (chain / imbalance)
+    with pytest.raises(ValueError):
+        O.OctreeBrickMesh(1, (2, 1, 2), [r0, r1])
+
+
 @pytest.mark.parametrize("p", [1, 2, 3])
 def test_general_hanging_mesh_reproduces_the_planar_one(p):
     """One planar interface built by both generators (HangingBrickMesh: round-2 known answers; RefinedBrickMesh with the upper
