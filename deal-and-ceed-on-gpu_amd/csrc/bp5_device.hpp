@@ -279,7 +279,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
     mf->n_cus = prop.multiProcessorCount;
   }
-  const int wg_per_cu = ((ABL & 2048) && !(ABL & (8388608 | 2097152)) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (Helmholtz / hanging-node builds: two per CU, registers)
+  const int wg_per_cu = ((ABL & 2048) && !(ABL & 8388608) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (the Helmholtz build: two per CU, registers)
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);

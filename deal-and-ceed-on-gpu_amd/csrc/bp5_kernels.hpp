@@ -1732,7 +1732,7 @@ struct BlockPass {
 };
 
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & (8388608 | 2097152))) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 8388608)) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;
@@ -2902,18 +2902,20 @@ template <int MODE>
 __device__ __forceinline__ void cgm_update_one(double &p, double &r, const double v, double &x, const double di, const bool done,
                                                const bool epi_odd, const double alpha, const double beta, const double aob)
 {
+  // explicit fma / mul: cgm_update_kernel and cgm_pack_updated_kernel (the early ghost gather) inline this into different contexts and
+  // must round identically -- a ghost copy of p is then bitwise its owner's p, whatever the compiler would have contracted
   if (done) {
-    if (epi_odd) x += alpha * p;
-    else x += (alpha + aob) * p + aob * di * r;
+    if (epi_odd) x = fma(alpha, p, x);
+    else x = fma(aob, di * r, fma(alpha + aob, p, x));
     return;
   }
   if (MODE == 0) {
-    p = -di * r;
+    p = -(di * r);
   } else {
-    if (MODE == 2) x += (alpha + aob) * p + aob * di * r;
-    const double rn = r + alpha * v;
+    if (MODE == 2) x = fma(aob, di * r, fma(alpha + aob, p, x));
+    const double rn = fma(alpha, v, r);
     r = rn;
-    p = beta * p - di * rn;
+    p = fma(beta, p, -(di * rn));
   }
 }
 // ZV: v is consumed here for the last time before the next operator application overwrites it -- an operator kernel that accumulates

@@ -33,11 +33,11 @@ def _free_port():
     return port
 
 
-def _run_ranks(world, args, out, timeout=420, worker=WORKER, delay_us=0):
+def _run_ranks(world, args, out, timeout=420, worker=WORKER, delay_us=0, extra_env=None):
     """delay_us: every transfer of the loopback transport lags that long behind its stream (BP5_LOOPBACK_DELAY_US); receives poison their
     destination with NaN until the message has landed (default of the transport) -- a missing cross-stream wait gives a wrong result"""
     assert os.path.exists(LOOPBACK_LIB), "libbp5_loopback.so missing: run __graft_entry__.build() (make -C .../csrc loopback)"
-    env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", BP5_LOOPBACK_DELAY_US=str(delay_us))
+    env = dict(os.environ, BP5_LIB=LOOPBACK_LIB, HSA_ENABLE_IPC_MODE_LEGACY="0", BP5_LOOPBACK_DELAY_US=str(delay_us), **(extra_env or {}))
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), out] + [str(a) for a in args], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -119,6 +119,22 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
     l2 = O.l2_norm_solution(pr.mesh, full["x_merged_default"])
     for z in ranks:
         assert abs(float(z["l2"]) - l2) < 1e-12 * l2
+
+
+def test_early_ghost_gather_gives_the_same_bits(tmp_path):
+    """The ghost gather of the NEW search direction travels under the vector update: cgm_pack_updated_kernel recomputes p at the interface
+    DoFs before the update kernel does (same arithmetic, explicit fma: cgm_update_one).  With BP5_EARLY_GATHER=0 the gather follows the
+    update kernel instead: every solve of every rank must give the same bits either way."""
+    args = [4, 8, 8, 12, 4, 4, 4, 1, 8, 56]
+    outs = []
+    for k, env in enumerate(({}, {"BP5_EARLY_GATHER": "0"})):
+        d = tmp_path / f"run{k}"
+        d.mkdir()
+        _run_ranks(2, args, str(d), extra_env=env)
+        outs.append([np.load(os.path.join(str(d), f"rank{r}.npz")) for r in range(2)])
+    for r in range(2):
+        for key in ("x_merged_unsplit", "x_merged_overlapped", "x_merged_default", "x_plain"):
+            assert np.array_equal(outs[0][r][key], outs[1][r][key]), (r, key)
 
 
 def test_bench_with_two_ranks_as_the_driver_launches_it():
