@@ -1614,7 +1614,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     // fused iteration across ranks: the values of the NEW p at the DoFs this rank sends are computed into the send buffer first, so the
     // ghost gather of p runs on the communication stream underneath the update kernel (which touches owned entries only); the operator
     // then just waits for the event
-    static const bool early_gather_enabled = [] { const char *e = getenv("BP5_EARLY_GATHER"); return !(e && e[0] == '0'); }(); // A/B knob for tools
+    const bool early_gather_enabled = [] { const char *e = getenv("BP5_EARLY_GATHER"); return !(e && e[0] == '0'); }(); // A/B knob for tools and tests (read per solve)
     const bool early_gather = fused && dist_solve && early_gather_enabled;
     auto gather_under_update = [&](int mode) -> int {
       BP5_TRY(halo_streams(mf));
@@ -1635,11 +1635,13 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
       launch_update(mode);
       KERNEL_CHECK();
       BP5_TRY(phase_mark(mf, 1));
+      const bool one_launch = fused && !mf->comm; // no all-reduce between the local sums and the scalar step
       if (fused) {
         uint32_t n_cols = 0;
         BP5_TRY(vmult(d, h, g, &n_cols));
         BP5_TRY(phase_mark(mf, 4));
-        hipLaunchKernelGGL(finalize_kernel<7>, dim3(7), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc + SC_R0, mf->d_st);
+        if (one_launch) hipLaunchKernelGGL(cgm_finalize4_kernel<true>, dim3(1), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc, mf->d_st);
+        else hipLaunchKernelGGL(cgm_finalize4_kernel<false>, dim3(1), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc, mf->d_st);
       } else {
         BP5_TRY(folded_vmult(d, h)); // (h: zeroed by cgm_init_kernel before the first, by the update kernel before every later application)
         BP5_TRY(phase_mark(mf, 4));
@@ -1649,10 +1651,13 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
       }
       KERNEL_CHECK();
       BP5_TRY(phase_mark(mf, 5));
-      BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
-      BP5_TRY(phase_mark(mf, 6));
-      hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
-      KERNEL_CHECK();
+      if (!one_launch) {
+        BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_R0, 7));
+        BP5_TRY(phase_mark(mf, 6));
+        hipLaunchKernelGGL(cgm_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
+        KERNEL_CHECK();
+      } else
+        BP5_TRY(phase_mark(mf, 6));
       BP5_TRY(phase_mark(mf, 7));
       if (mf->phase.on) ++mf->phase.it;
       if (check > 0 && it % check == 0 && it < prm->max_iter) {

@@ -3025,7 +3025,11 @@ static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, co
   block_reduce_store<7>(acc, partials);
 }
 // scalars of one merged iteration (solver.h:496-506,533)
-static __global__ void cgm_control_kernel(double *sc, int *st)
+static __global__ void cgm_control_kernel(double *sc, int *st);
+// Fused iteration (D == 1: rows 4-6 of the partial sums mirror rows 2, 1, 3): ONE workgroup sums the four distinct rows in the fixed tree
+// order of finalize_kernel (same bits) and -- on one rank, where no all-reduce sits in between -- takes the scalar step right away: one
+// launch instead of two (the earlier one-launch probe used seven workgroups and a device-scope fence, which cost more than it saved)
+__device__ __forceinline__ void cgm_control_step(double *sc, int *st)
 {
   if (st[ST_DONE]) { st[ST_PENDING] = 0; return; }
   const double *R = sc + SC_R0;
@@ -3041,6 +3045,37 @@ static __global__ void cgm_control_kernel(double *sc, int *st)
   if (res <= sc[SC_TOL] || it >= st[ST_MAXIT]) { st[ST_DONE] = 1; st[ST_PENDING] = 1; return; }
   sc[SC_BETA] = alpha * (R[4] + alpha * R[5]) / R[6];
 }
+template <bool CONTROL>
+__global__ void __launch_bounds__(VB) cgm_finalize4_kernel(const double *partials, int nblk, double *sc, int *st)
+{
+  if (st[ST_DONE]) { // frozen solve: nothing to sum; the scalar step still clears the pending flag
+    if (CONTROL && threadIdx.x == 0) cgm_control_step(sc, st);
+    return;
+  }
+  __shared__ double red[VB];
+  double *out = sc + SC_R0;
+  for (int k = 0; k < 4; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += VB) s += partials[k * PARTIAL_STRIDE + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = VB / 2; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out[k] = red[0];
+      if (k == 1) out[5] = red[0]; // v.Dv = v.v
+      if (k == 2) out[4] = red[0]; // r.Dv = r.v
+      if (k == 3) out[6] = red[0]; // r.Dr = r.r
+    }
+    __syncthreads();
+  }
+  if (CONTROL && threadIdx.x == 0) cgm_control_step(sc, st);
+}
+
+static __global__ void cgm_control_kernel(double *sc, int *st) { cgm_control_step(sc, st); }
+
 // merged init: r = -b, x = 0, partial r.r
 static __global__ void __launch_bounds__(VB) cgm_init_kernel(const double *b, double *x, double *r, double *p, double *v, size_t n,
                                                      double *partials)

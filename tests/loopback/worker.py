@@ -78,6 +78,10 @@ def main():
         solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_again")
         solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped_again")
         solve(pkg.SolverCG, 1, True, "plain_overlapped")
+        os.environ["BP5_EARLY_GATHER"] = "0"       # the ghost gather of p AFTER the update kernel instead of underneath it: the same bits
+        solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_late_gather")
+        solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped_late_gather")
+        del os.environ["BP5_EARLY_GATHER"]
         res["norms"] = np.asarray(norms)
         # Jacobi-preconditioned merged CG (diagonal assembled across ranks)
         op.mf_data.set_overlap(2)
