@@ -7,6 +7,7 @@
 //   bp5_step64 bench <degree> <n> <iterations> <repetitions>     prints pcg-standard / pcg-merged / vmult lines
 //   bp5_step64 hanging <degree> <prefix>                         externally generated 2:1 refined mesh (<prefix>_l2g/_coords/_constrained/
 //                                                                _mask/_src.bin): functor path with resolve_hanging_nodes vs library kernel
+//   bp5_step64 helmholtz_native <degree> <n> <prefix>            the same through the library's native fused Helmholtz kernel
 //   bp5_step64 helmholtz <degree> <n> <prefix>                   HelmholtzProblem::solve of step-64/step-64.cu on n^3 cells of the
 //                                                                unit cube: the functor operator inside the library's CG solvers
 #include <cmath>
@@ -228,6 +229,41 @@ private:
   double *coef = nullptr;
 };
 
+// ---- the same operator on the library's NATIVE fused Helmholtz kernel (bp5_mf_set_operator(BP5_OP_HELMHOLTZ)): what a maintainer of
+// step-64 switches to once the functor version works -- same class surface, plus coef(): the solvers then run it as the library's own
+// operator (fused kernels, CG dot products inside the operator on cell bricks) instead of calling back into vmult.
+template <int dim, int fe_degree>
+class HelmholtzOperatorNative {
+public:
+  explicit HelmholtzOperatorNative(const bp5_mesh_view &mv)
+  {
+    bp5_mf_desc d{};
+    d.dim = dim; d.degree = fe_degree; d.quadrature = BP5_QUAD_GAUSS; d.coefficient = BP5_COEF_STEP64; // a(x) of VaryingCoefficientFunctor
+    d.n_cells = mv.n_cells; d.n_interior_cells = mv.n_interior_cells; d.n_owned = mv.n_owned; d.n_ghost = mv.n_ghost;
+    d.local_to_global_host = mv.local_to_global_host; d.node_coords_host = mv.node_coords_host;
+    d.constrained_host = mv.constrained_host; d.n_constrained = mv.n_constrained;
+    d.n_cell_blocks = mv.n_cell_blocks; d.cell_block_offsets_host = mv.cell_block_offsets_host;
+    mf_data.reinit(d);
+    check(bp5_mf_set_operator(mf_data.handle(), BP5_OP_HELMHOLTZ));
+    size_t nc;
+    check(bp5_mf_coef_size(mf_data.handle(), &nc)); // seven planes: six merged + a JxW
+    check(bp5_vec_alloc(nc, &coef7));
+    check(bp5_mf_compute_merged_metric(mf_data.handle(), coef7));
+  }
+  ~HelmholtzOperatorNative() { bp5_vec_free(coef7); }
+  void vmult(DeviceVector &dst, const DeviceVector &src) const
+  { // HelmholtzOperator::vmult, step-64/step-64.cu:283-300, in one call
+    check(bp5_apply(mf_data.handle(), coef7, static_cast<const double *>(src.get_values()), dst.get_values(), 1));
+  }
+  void initialize_dof_vector(DeviceVector &v) const { mf_data.initialize_dof_vector(v); }
+  bp5_mf *handle() const { return mf_data.handle(); }
+  const double *coef() const { return coef7; }
+  CUDAWrappers::MatrixFree<dim, double> mf_data;
+
+private:
+  double *coef7 = nullptr;
+};
+
 static std::vector<double> download(const double *d, size_t n)
 {
   std::vector<double> h(n);
@@ -432,7 +468,7 @@ static void dump(const std::string &path, const std::vector<double> &v);
 // HelmholtzProblem<dim, fe_degree>::run for ONE cycle (step-64/step-64.cu:505-530,602-616,634-663): n^3 cells of the unit cube,
 // f == 1, zero Dirichlet values, a(x) = 10 / (0.05 + 2 |x|^2), identity preconditioner, tolerance 1e-12 ||b||, at most n_dofs
 // iterations; prints the iteration counts and the L2 norm of the solution for SolverCG and SolverCGFullMerge.
-template <int fe_degree>
+template <int fe_degree, bool NATIVE = false>
 static int run_helmholtz(uint32_t ncell, const std::string &prefix)
 {
   constexpr int dim = 3;
@@ -442,7 +478,7 @@ static int run_helmholtz(uint32_t ncell, const std::string &prefix)
   check(bp5_mesh_create_brick(&md, &mesh));
   bp5_mesh_view mv;
   check(bp5_mesh_view_get(mesh, &mv));
-  HelmholtzOperator<dim, fe_degree> system_matrix_dev(mv);
+  typename std::conditional<NATIVE, HelmholtzOperatorNative<dim, fe_degree>, HelmholtzOperator<dim, fe_degree>>::type system_matrix_dev(mv);
   DeviceVector solution_dev, system_rhs_dev;
   system_matrix_dev.initialize_dof_vector(solution_dev);
   system_matrix_dev.initialize_dof_vector(system_rhs_dev);
@@ -528,6 +564,12 @@ int main(int argc, char **argv)
       switch (atoi(argv[2])) {
         case 2: return run_hanging<2>(argv[3]);
         case 3: return run_hanging<3>(argv[3]);
+      }
+    } else if (argc >= 5 && !strcmp(argv[1], "helmholtz_native")) {
+      switch (atoi(argv[2])) {
+        case 2: return run_helmholtz<2, true>(atoi(argv[3]), argv[4]);
+        case 3: return run_helmholtz<3, true>(atoi(argv[3]), argv[4]);
+        case 4: return run_helmholtz<4, true>(atoi(argv[3]), argv[4]);
       }
     } else if (argc >= 5 && !strcmp(argv[1], "helmholtz")) {
       switch (atoi(argv[2])) {

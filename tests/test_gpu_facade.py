@@ -77,14 +77,14 @@ def test_reference_main_program_cycles():
 
 
 @pytest.mark.parametrize("p,n", [(3, 2), (2, 3)])
-def test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, p, n):
+def test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, p, n, mode="helmholtz"):
     """HelmholtzProblem::solve (step-64/step-64.cu:505-530): the reference's solvers take ANY operator with vmult
     (bp5/solver.h:25-30,377,475).  The example's HelmholtzOperator is a user device functor behind the facade; SolverCG and
     SolverCGFullMerge reach it through bp5_cg_solve_operator.  Checked against the oracle's CG on apply_helmholtz_cells.
     p = 3 on 2^3 cells (343 DoFs) is the first cycle of the step-64 tutorial, whose printed `solution norm` is remembered
     as ~0.0205439 (a soft cross-check from outside /root/reference, reported, not asserted tightly)."""
     prefix = str(tmp_path / "h")
-    r = subprocess.run([EXE, "helmholtz", str(p), str(n), prefix], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, mode, str(p), str(n), prefix], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     vals = {k: float(v) for k, v in re.findall(r"^(\w+) ([0-9.e+-]+)", r.stdout, flags=re.M)}
     pr = O.Problem(p, (n, n, n), O.QUAD_GAUSS, h=1.0 / n)
@@ -111,6 +111,14 @@ def test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, 
         print(f"step-64 cycle 0 (p=3, 8 cells, 343 DoFs): solution norm {norm_ref:.7f} (GPU {vals['helmholtz_plain_norm']:.7f}); "
               f"remembered tutorial value {soft}; difference {norm_ref - soft:+.2e}")
         assert m.n_dofs == 343 and abs(norm_ref - soft) < 1e-7               # agrees to the six digits remembered
+
+
+@pytest.mark.parametrize("p,n", [(3, 2), (2, 4), (4, 3)])
+def test_step64_helmholtz_solve_on_the_native_kernel(tmp_path, p, n):
+    """The same program with the example's HelmholtzOperatorNative (bp5_mf_set_operator(BP5_OP_HELMHOLTZ): the library's fused Helmholtz
+    kernel behind the same class surface; it exposes coef(), so SolverCG / SolverCGFullMerge run it as the library's own operator): the
+    same right-hand side, iteration counts, solution vectors and norms as the oracle's CG."""
+    test_step64_helmholtz_solve_through_the_operator_agnostic_solvers(tmp_path, p, n, mode="helmholtz_native")
 
 
 @pytest.mark.parametrize("p,general", [(2, False), (3, False), (2, True), (3, True)])
