@@ -180,7 +180,7 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
   for (auto &kv : mf->march_plans) { hipFree(kv.second.team_off); hipFree(kv.second.entries); }
   for (auto &kv : mf->plans) {
     auto &q = kv.second;
-    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile};
+    void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.lattice, q.cell_pos, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile};
     for (void *x : pp) if (x) hipFree(x);
     if (q.wg_blocks) { for (auto &w : *q.wg_blocks) hipFree(w.second); delete q.wg_blocks; }
   }
@@ -274,6 +274,15 @@ extern "C" int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *
   *n_blocks = dp->n_groups;
   *max_runs = dp->max_runs;
   *packed_indices = dp->packed != nullptr;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_block_plan_lattice(bp5_mf *mf, uint32_t *n_lattice_blocks)
+{
+  if (!mf || !n_lattice_blocks) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp, 64));
+  *n_lattice_blocks = dp->n_lattice_blocks;
   return BP5_OK;
 }
 extern "C" int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective)
@@ -413,6 +422,138 @@ extern "C" int bp5_mf_get_data(bp5_mf *mf, int color, bp5_mf_data *out)
 
 // ------------------------------------------------------------------------------------ operator
 
+// Structured cell blocks ("lattice" blocks).  A block is a lattice block when (1) its cells form a full box of bx x by x bz cells that are
+// face neighbours with parallel local axes, and (2) its DoFs are numbered entity by entity: the DoFs of each of the 27 lattice entities of
+// the box (interior, 6 faces, 12 edges, 8 corners of its (bx p + 1) x (by p + 1) x (bz p + 1) node lattice) are consecutive, x fastest --
+// what a brick-major numbering (bp5_mesh_create_brick: dof_numbering = 1) produces.  The list slot and the DoF of every cell-local entry
+// then follow in closed form from the cell's position (cx, cy, cz) and the entry's (i, j, k):  I = cx p + i, ..., entity = class(I) +
+// 3 class(J) + 9 class(K) (class: 0 at the low plane, 2 at the high plane, 1 between), offset = interior coordinates in mixed radix --
+// the kernels compute both instead of reading 2 bytes per entry (2 r bytes per DoF of HBM traffic).  Recognition is topological (shared
+// face corners), the numbering is verified entry by entry; any block that fails keeps the packed stream.
+// out `lat`: [n_blocks][BLOCK_LATTICE_WORDS]: slots of the 27 entities, their first DoFs, then bx | by << 8 | bz << 16 | 1 << 31 (0: no lattice).
+static uint32_t detect_lattice_blocks(const uint32_t *l2g, int n, const std::vector<uint32_t> &cell_off, const std::vector<uint32_t> &list_off,
+                                      const std::vector<uint32_t> &list_dofs, std::vector<uint32_t> &lat, std::vector<uint16_t> &cpos)
+{
+  const int p = n - 1, n2 = n * n, n3 = n2 * n;
+  const size_t n_blocks = cell_off.size() - 1;
+  lat.assign(n_blocks * BLOCK_LATTICE_WORDS, 0u);
+  cpos.assign(cell_off.back(), 0);
+  uint32_t n_ok = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : n_ok)
+  for (int64_t g = 0; g < (int64_t)n_blocks; ++g) {
+    const uint32_t c0 = cell_off[g], nc = cell_off[g + 1] - c0;
+    if (nc == 0 || nc > 4096) continue;
+    auto L = [&](uint32_t c, int i, int j, int k) { return l2g[(size_t)(c0 + c) * n3 + i + n * (j + n * k)]; };
+    // faces by their four corner DoFs: face f = 2 d + side of cell c
+    auto face_key = [&](uint32_t c, int d, int side, uint32_t (&key)[4]) {
+      int q = 0;
+      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+          int ijk[3];
+          ijk[d] = side * p;
+          ijk[(d + 1) % 3] = a * p;
+          ijk[(d + 2) % 3] = b * p;
+          key[q++] = L(c, ijk[0], ijk[1], ijk[2]);
+        }
+    };
+    // neighbours: sort the 6 nc faces by their keys; a +side face of one cell and the -side face of another with the same corners meet
+    struct Face { uint32_t k[4]; uint32_t cell; int d, side; };
+    std::vector<Face> faces;
+    faces.reserve(6 * (size_t)nc);
+    for (uint32_t c = 0; c < nc; ++c)
+      for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+          Face f;
+          face_key(c, d, side, f.k);
+          f.cell = c; f.d = d; f.side = side;
+          faces.push_back(f);
+        }
+    std::sort(faces.begin(), faces.end(), [](const Face &a, const Face &b) { return std::lexicographical_compare(a.k, a.k + 4, b.k, b.k + 4); });
+    std::vector<uint32_t> nbr(6 * (size_t)nc, UINT32_MAX); // [cell][2 d + side]
+    for (size_t f = 0; f + 1 < faces.size(); ++f) {
+      const Face &a = faces[f], &b = faces[f + 1];
+      if (std::equal(a.k, a.k + 4, b.k) && a.d == b.d && a.side != b.side && a.cell != b.cell) {
+        nbr[6 * (size_t)a.cell + 2 * a.d + a.side] = b.cell;
+        nbr[6 * (size_t)b.cell + 2 * b.d + b.side] = a.cell;
+      }
+    }
+    std::vector<int> pos(3 * (size_t)nc, INT32_MIN);
+    std::vector<uint32_t> queue{0};
+    pos[0] = pos[1] = pos[2] = 0;
+    bool ok = true;
+    for (size_t qh = 0; qh < queue.size() && ok; ++qh) { // breadth-first over face neighbours
+      const uint32_t c = queue[qh];
+      for (int d = 0; d < 3 && ok; ++d)
+        for (int side = 0; side < 2 && ok; ++side) {
+          const uint32_t o = nbr[6 * (size_t)c + 2 * d + side];
+          if (o == UINT32_MAX) continue;
+          int want[3] = {pos[3 * c], pos[3 * c + 1], pos[3 * c + 2]};
+          want[d] += side ? 1 : -1;
+          if (pos[3 * o] == INT32_MIN) {
+            pos[3 * o] = want[0]; pos[3 * o + 1] = want[1]; pos[3 * o + 2] = want[2];
+            queue.push_back(o);
+          } else if (pos[3 * o] != want[0] || pos[3 * o + 1] != want[1] || pos[3 * o + 2] != want[2])
+            ok = false;
+        }
+    }
+    if (!ok || queue.size() != nc) continue;
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (uint32_t c = 0; c < nc; ++c)
+      for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], pos[3 * c + d]); hi[d] = std::max(hi[d], pos[3 * c + d]); }
+    const int bx = hi[0] - lo[0] + 1, by = hi[1] - lo[1] + 1, bz = hi[2] - lo[2] + 1;
+    if ((int64_t)bx * by * bz != (int64_t)nc || bx > 15 || by > 15 || bz > 15) continue;
+    std::vector<uint32_t> cell_at((size_t)nc, UINT32_MAX);
+    for (uint32_t c = 0; c < nc && ok; ++c) {
+      const size_t at = (pos[3 * c] - lo[0]) + (size_t)bx * ((pos[3 * c + 1] - lo[1]) + (size_t)by * (pos[3 * c + 2] - lo[2]));
+      if (cell_at[at] != UINT32_MAX) ok = false;
+      cell_at[at] = c;
+    }
+    if (!ok) continue;
+    const int N[3] = {bx * p, by * p, bz * p};
+    auto cls = [&](int X, int d) { return X == 0 ? 0 : X == N[d] ? 2 : 1; };
+    auto dof_at = [&](int I, int J, int K) { // the DoF at a lattice point, through any cell that holds it
+      const int cx = std::min(I / p, bx - 1), cy = std::min(J / p, by - 1), cz = std::min(K / p, bz - 1);
+      return L(cell_at[cx + (size_t)bx * (cy + (size_t)by * cz)], I - cx * p, J - cy * p, K - cz * p);
+    };
+    uint32_t ent_dof[27];
+    for (int e = 0; e < 27; ++e) {
+      const int eI = e % 3, eJ = (e / 3) % 3, eK = e / 9;
+      // an entity that does not exist (a direction without interior points: N == 1 has none between the planes) is never referenced
+      const int I = eI == 0 ? 0 : eI == 2 ? N[0] : 1, J = eJ == 0 ? 0 : eJ == 2 ? N[1] : 1, K = eK == 0 ? 0 : eK == 2 ? N[2] : 1;
+      ent_dof[e] = (I <= N[0] && J <= N[1] && K <= N[2] && !(eI == 1 && N[0] < 2) && !(eJ == 1 && N[1] < 2) && !(eK == 1 && N[2] < 2)) ? dof_at(I, J, K) : 0u;
+    }
+    for (uint32_t c = 0; c < nc && ok; ++c) { // the numbering, entry by entry
+      const int cx = pos[3 * c] - lo[0], cy = pos[3 * c + 1] - lo[1], cz = pos[3 * c + 2] - lo[2];
+      for (int k = 0; k < n && ok; ++k)
+        for (int j = 0; j < n && ok; ++j)
+          for (int i = 0; i < n; ++i) {
+            const int I = cx * p + i, J = cy * p + j, K = cz * p + k;
+            const int eI = cls(I, 0), eJ = cls(J, 1), eK = cls(K, 2);
+            const uint32_t LX = eI == 1 ? N[0] - 1 : 1, LY = eJ == 1 ? N[1] - 1 : 1;
+            const uint32_t off = (eI == 1 ? I - 1 : 0) + LX * ((eJ == 1 ? J - 1 : 0) + LY * (eK == 1 ? K - 1 : 0));
+            if (L(c, i, j, k) != ent_dof[eI + 3 * eJ + 9 * eK] + off) { ok = false; break; }
+          }
+    }
+    if (!ok) continue;
+    uint32_t *row = lat.data() + (size_t)g * BLOCK_LATTICE_WORDS;
+    const uint32_t *lb = list_dofs.data() + list_off[g], *le = list_dofs.data() + list_off[g + 1];
+    for (int e = 0; e < 27 && ok; ++e) {
+      const uint32_t *it = std::lower_bound(lb, le, ent_dof[e], [](uint32_t a, uint32_t b) { return (a & 0x7fffffffu) < b; });
+      const int eI = e % 3, eJ = (e / 3) % 3, eK = e / 9;
+      const bool exists = !(eI == 1 && N[0] < 2) && !(eJ == 1 && N[1] < 2) && !(eK == 1 && N[2] < 2);
+      if (exists && (it == le || (*it & 0x7fffffffu) != ent_dof[e])) ok = false;
+      row[e] = exists ? (uint32_t)(it - lb) : 0u;
+      row[27 + e] = ent_dof[e];
+    }
+    if (!ok) { std::fill(row, row + BLOCK_LATTICE_WORDS, 0u); continue; }
+    row[54] = (uint32_t)bx | (uint32_t)by << 8 | (uint32_t)bz << 16 | 0x80000000u;
+    for (uint32_t c = 0; c < nc; ++c)
+      cpos[c0 + c] = (uint16_t)((pos[3 * c] - lo[0]) | (pos[3 * c + 1] - lo[1]) << 4 | (pos[3 * c + 2] - lo[2]) << 8);
+    ++n_ok;
+  }
+  return n_ok;
+}
+
 // key > 0: uniform teams of `key` cells (team kernel); key < 0: cell blocks walked in passes of
 // -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
 int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
@@ -482,6 +623,17 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       BP5_TRY(upload(&dp.pos, pos2.data(), pos2.size()));
       BP5_TRY(upload(&dp.gidx, gidx.data(), gidx.size()));
       if (!packed.empty()) BP5_TRY(upload(&dp.packed, packed.data(), packed.size()));
+      if (!packed.empty()) { // lattice blocks: recognised and VERIFIED entry by entry here; everything else keeps the packed stream
+        std::vector<uint32_t> lat;
+        std::vector<uint16_t> cpos;
+        dp.n_lattice_blocks = detect_lattice_blocks(mf->h_l2g.data(), n, h.group_cell_off, h.off, h.dofs, lat, cpos);
+        const bool lattice_enabled = [] { const char *e = getenv("BP5_LATTICE_INDICES"); return !(e && e[0] == '0'); }(); // A/B knob for tools and tests (read when the plan is built)
+        if (dp.n_lattice_blocks && lattice_enabled) {
+          BP5_TRY(upload(&dp.lattice, lat.data(), lat.size()));
+          BP5_TRY(upload(&dp.cell_pos, cpos.data(), cpos.size()));
+        } else
+          dp.n_lattice_blocks = 0;
+      }
     } else
       BP5_TRY(upload(&dp.pos, h.pos.data(), h.pos.size()));
     BP5_TRY(upload(&dp.cell_round, h.cell_round.data(), h.cell_round.size()));

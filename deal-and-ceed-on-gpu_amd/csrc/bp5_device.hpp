@@ -129,6 +129,11 @@ struct bp5_mf {
     double *partial = nullptr;
     uint32_t *cell_off = nullptr, *pass_cell = nullptr, *pass_off = nullptr, *run_off = nullptr, *runs = nullptr, *gidx = nullptr;
     uint16_t *packed = nullptr;
+    // lattice form of the packed indices (structured bricks: every cell-local DoF's list slot and DoF follow in closed form from the cell's
+    // position in its brick -- no per-DoF index stream at all): per block 64 words (bp5_kernels.hpp: BLOCK_LATTICE_WORDS), per cell its position
+    uint32_t *lattice = nullptr;
+    uint16_t *cell_pos = nullptr;
+    uint32_t n_lattice_blocks = 0;
     std::vector<double> h_cost;                       // [n_groups+1] prefix sum of the estimated cost of the blocks (pass units)
     // block ranges of the persistent workgroups, one device array per (n_wg, first block, end block) ever launched: the
     // interior / boundary ranges of the overlapped schedule alternate, nothing is freed or re-uploaded inside a solve
@@ -255,13 +260,16 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -CPT, &dp));
   const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
-  const size_t lds = ((size_t)CPT * tile_cs + ((ABL & 524288) ? 2 : 1) * (size_t)dp->max_list) * sizeof(double) + ((ABL & 16384) ? 4 * BLOCK_MAX_RUNS * sizeof(uint32_t) : 0);
+  const size_t lds = ((size_t)CPT * tile_cs + ((ABL & 524288) ? 2 : 1) * (size_t)dp->max_list) * sizeof(double) +
+                     ((ABL & 16384) ? (4 * BLOCK_MAX_RUNS + 2 * BLOCK_LATTICE_WORDS) * sizeof(uint32_t) : 0); // run tables + lattice tables (two blocks each)
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
   if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 128 runs per block: packed indices unavailable");
+  if ((ABL & 16777216) && !(dp->lattice && dp->n_lattice_blocks == dp->n_groups)) return fail(BP5_ERR_INVALID, "the lattice build needs a plan of lattice blocks only");
   if (lds > 160 * 1024) return fail(BP5_ERR_UNSUPPORTED, "cell block does not fit in LDS; pass smaller cell blocks");
   BlockPlan bp{}; // value-initialised: a field this launcher forgets is null, not garbage
   bp.pass_cell = dp->pass_cell; bp.pass_off = dp->pass_off; bp.off = dp->off; bp.dofs = dp->dofs; bp.pos = dp->pos; bp.gidx = dp->gidx;
   bp.packed = dp->packed;
+  bp.lattice = dp->lattice; bp.cell_pos = dp->cell_pos;
   bp.cell_round = dp->cell_round; bp.blk_rounds = dp->team_rounds; bp.partial = dp->partial; bp.n_blocks = dp->n_groups;
   bp.run_off = dp->run_off; bp.runs = dp->runs; bp.max_list = dp->max_list;
   // a block-aligned cell range: only these blocks run, accumulate mode; DoFs shared with other blocks go to dst by
@@ -740,9 +748,17 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
       bp5_mf::DevPlan *dp_ = nullptr;
       BP5_TRY(get_plan_raw(mf, -(256 / LPCB), &dp_));
       if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 56 needs packed indices (<= 128 runs per cell block) at this degree");
+      constexpr int LATT = 16777216; // every block a lattice block: closed-form indices, no per-DoF index stream
+      const bool lattice = dp_->lattice && dp_->n_lattice_blocks == dp_->n_groups;
+      if (mf->fuse.on && lattice)
+        return coll ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite)
+                    : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite);
       if (mf->fuse.on)
         return coll ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite)
                     : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite);
+      if (lattice)
+        return coll ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite)
+                    : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite);
       return coll ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
                   : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);
     }
@@ -771,11 +787,19 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite);
         }
+        constexpr int LATT = 16777216; // every block a lattice block: closed-form indices, no per-DoF index stream
+        const bool lattice = variant == 56 && dp_->packed && dp_->lattice && dp_->n_lattice_blocks == dp_->n_groups;
         if (mf->fuse.on) { // the solver asked for the fused dot products (only ever with the packed default shape)
           if (!dp_->packed || variant != 56) return fail(BP5_ERR_INVALID, "fused dot products need the packed block kernel");
+          if (lattice)
+            return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite)
+                        : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite);
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite);
         }
+        if (lattice)
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite);
         if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);

@@ -484,8 +484,30 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
       base += dir[0].S[cl & 1] * dir[1].S[(cl >> 1) & 1] * dir[2].S[(cl >> 2) & 1];
     }
   }
+  // position of (I, J) inside a z-plane that is exchanged between ranks (the ghost plane K == Kbot of rank > 0 = the top plane of the rank
+  // below).  Lexicographic, or (block-major numbering) the 2-D analogue of the owned numbering: footprint interiors of the bricks first,
+  // then the lines between them, then their crossings -- every entity contiguous, x fastest -- so that the bricks of the ghost-touching
+  // layer are lattice blocks like all others (bp5_device.hip: detect_lattice_blocks).  Sender and receiver use the same function.
+  uint64_t plane_class_base[4] = {0, 0, 0, 0};
+  if (d->dof_numbering == 1) {
+    uint64_t base2 = 0;
+    for (int cl = 0; cl < 4; ++cl) { // (kx, ky) = (0,0), (1,0), (0,1), (1,1)
+      plane_class_base[cl] = base2;
+      base2 += dir[0].S[cl & 1] * dir[1].S[(cl >> 1) & 1];
+    }
+  }
+  auto plane_pos = [&](uint64_t I, uint64_t J) -> uint64_t {
+    if (d->dof_numbering != 1) return I + NX * J;
+    const uint64_t c2[2] = {I, J};
+    int k[2]; uint64_t sl[2], in[2], Ls[2], Pr[2], Ss[2];
+    for (int e = 0; e < 2; ++e) {
+      k[e] = dir[e].kind[c2[e]]; sl[e] = dir[e].slot[c2[e]]; in[e] = dir[e].in[c2[e]];
+      Ls[e] = dir[e].L[k[e]][sl[e]]; Pr[e] = dir[e].Pre[k[e]][sl[e]]; Ss[e] = dir[e].S[k[e]];
+    }
+    return plane_class_base[k[0] + 2 * k[1]] + Pr[1] * Ss[0] + Ls[1] * Pr[0] + in[0] + Ls[0] * in[1];
+  };
   auto local_of = [&](uint64_t I, uint64_t J, uint64_t K) -> uint32_t {
-    if (K < Kown0) return (uint32_t)(n_owned + I + NX * J); // ghost plane K == Kbot, owned by rank-1
+    if (K < Kown0) return (uint32_t)(n_owned + plane_pos(I, J)); // ghost plane K == Kbot, owned by rank-1
     if (d->dof_numbering != 1) return (uint32_t)(I + NX * (J + NY * (K - Kown0)));
     const uint64_t c3[3] = {I, J, K - Kown0};
     int k[3]; uint64_t sl[3], in[3], Ls[3], Pr[3], Ss[3];
@@ -573,10 +595,12 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
     m->send_offsets.push_back((uint32_t)m->send_indices.size());
     m->recv_offsets.push_back((uint32_t)plane);
   }
-  if (r < R - 1) { // neighbour r+1: we send our top plane, receive nothing
+  if (r < R - 1) { // neighbour r+1: we send our top plane (in the order of ITS ghost range), receive nothing
     m->neighbors.push_back(r + 1);
+    std::vector<uint32_t> by_pos(plane);
     for (uint64_t J = 0; J < NY; ++J)
-      for (uint64_t I = 0; I < NX; ++I) m->send_indices.push_back(local_of(I, J, Ktop));
+      for (uint64_t I = 0; I < NX; ++I) by_pos[plane_pos(I, J)] = local_of(I, J, Ktop);
+    m->send_indices.insert(m->send_indices.end(), by_pos.begin(), by_pos.end());
     m->send_offsets.push_back((uint32_t)m->send_indices.size());
     m->recv_offsets.push_back(m->recv_offsets.back());
   }

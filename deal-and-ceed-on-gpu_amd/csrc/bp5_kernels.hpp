@@ -1159,6 +1159,7 @@ constexpr int BLOCK_MAX_RUNS = 128;
 // (builds with fused dot products write src there: copy_constrained_values folded into the write-out); DoF indices < 2^30
 constexpr uint32_t BLOCK_DOF_MASK = 0x3fffffffu, BLOCK_DOF_CONSTRAINED = 0x40000000u;
 constexpr int PARTIAL_STRIDE = 8192;   // row length of the partial-sum array d_partials[8][PARTIAL_STRIDE] (all reducing kernels)
+constexpr int BLOCK_LATTICE_WORDS = 64; // per block: 27 entity slots, 27 entity DoFs, dims | flag, padding (bp5_device.hip: detect_lattice_blocks)
 constexpr int BLOCK_PACK_OFF_BITS = 9;                              // packed index = run << 9 | offset (runs are cut at 512 entries)
 constexpr int BLOCK_PACK_MAX_RUNS = 1 << (16 - BLOCK_PACK_OFF_BITS); // 128 == BLOCK_MAX_RUNS
 static_assert(BLOCK_PACK_MAX_RUNS <= BLOCK_MAX_RUNS, "the LDS run table holds every packable run");
@@ -1173,6 +1174,10 @@ struct BlockPlan {
   // 512 entries and where the Dirichlet flag changes, at most 128 per block -- a boundary brick of a slab mesh with its ghost rows has ~70); list slot = run_slot[run] + offset, DoF = run_dof[run] + offset, both from the
   // block's run table in LDS -- the local_to_global stream is not read at all
   const uint16_t *packed;     // [n_cells*n^3], pair layout
+  // lattice blocks (structured bricks, recognised and verified on the host: detect_lattice_blocks): list slot and DoF of every cell-local
+  // entry follow in closed form from the cell's position in its block and the block's 27 entity bases -- the packed stream is not read
+  const uint32_t *lattice;    // [n_blocks][BLOCK_LATTICE_WORDS] or NULL: 27 entity slots, 27 entity DoFs, bx | by << 8 | bz << 16 | 1 << 31 (0: packed block)
+  const uint16_t *cell_pos;   // [n_cells] cx | cy << 4 | cz << 8 (lattice blocks)
   const uint8_t *cell_round;  // [n_cells] accumulation round inside the pass (0 when conflict-free)
   const uint8_t *blk_rounds;  // [n_blocks] rounds needed by the block's passes (normally 1)
   double *partial;            // [off[n_blocks]]
@@ -1209,6 +1214,7 @@ struct PassRegs {
   uint32_t idx[n];
   uint32_t ent; // pass_cell entry
   uint32_t mask; // hanging-node builds: the cell's constraint mask (BP5_HANG_*)
+  uint32_t cpos; // lattice blocks: the cell's position in its block
   int round;
   bool active;
 };
@@ -1254,6 +1260,11 @@ struct BlockPass {
   // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
   // workgroup needs a third of the tile memory: 4x4x4 accumulator + tiles = 47 KB -> three workgroups per CU
   static constexpr bool PACK = (ABL & 262144) != 0; // packed (run, offset) indices, decoded through the LDS run table
+  // LATT: EVERY block of the plan is a lattice block (bp5_device.hip: detect_lattice_blocks) -- list slots and DoFs in closed form from the
+  // cell's position in its block, no per-DoF index stream at all (a build of its own: the headline kernel sits at the register budget of
+  // three waves per SIMD, and this path needs fewer registers than the packed one, both together more)
+  static constexpr bool LATT = (ABL & 16777216) != 0;
+  static_assert(!LATT || PACK, "lattice build: on top of the packed shape (run tables for the write-out)");
   // STAGE: the brick's src values are staged ONCE in an LDS array indexed like the accumulator (block start: coalesced loads
   // along the runs of the brick's sorted DoF list); the cells gather from LDS -- no global gather instructions, every src
   // entry of a brick crosses HBM/L2 once instead of once per cell that touches it
@@ -1273,7 +1284,8 @@ struct BlockPass {
   {
     r.active = lane_ok && exists && !(r.ent >> 31);
     const uint64_t cell = r.ent & 0x7fffffffu;
-    if constexpr (PACK) load_pencil_idx<n, uint16_t>(bp.packed + cell * n3, abm, r.ps); // decoded by decode_and_gather
+    if constexpr (LATT) r.cpos = bp.cell_pos[cell];
+    else if constexpr (PACK) load_pencil_idx<n, uint16_t>(bp.packed + cell * n3, abm, r.ps); // decoded by decode_and_gather
     else {
       load_pencil_idx<n, uint32_t>(bp.gidx + cell * n3, abm, r.idx);
       load_pencil_idx<n, uint16_t>(bp.pos + cell * n3, abm, r.ps);
@@ -1303,8 +1315,32 @@ struct BlockPass {
   }
   // PACK: r.ps holds the packed entries of the pass; turn them into list slots (kept in r.ps for the accumulation) and
   // DoF indices through the run table `rt` of the pass's block, and start the gather
-  static __device__ __forceinline__ void decode_and_gather(const ApplyArgs &a, R &r, const uint32_t *rt, const double *staged = nullptr)
+  static __device__ __forceinline__ void decode_and_gather(const ApplyArgs &a, R &r, const uint32_t *rt, const double *staged = nullptr,
+                                                           const uint32_t *lt = nullptr, int a_ = 0, int b_ = 0)
   {
+    if constexpr (LATT) { // lattice blocks: slots and DoFs in closed form (detect_lattice_blocks verified every entry)
+      const uint32_t hdr = lt[54];
+      const int NXl = (int)(hdr & 255u) * P, NYl = (int)((hdr >> 8) & 255u) * P, NZl = (int)((hdr >> 16) & 255u) * P;
+      const int I = (int)(r.cpos & 15u) * P + a_, J = (int)((r.cpos >> 4) & 15u) * P + b_, K0 = (int)(r.cpos >> 8) * P;
+      const int eI = I == 0 ? 0 : I == NXl ? 2 : 1, eJ = J == 0 ? 0 : J == NYl ? 2 : 1;
+      const uint32_t LX = eI == 1 ? (uint32_t)(NXl - 1) : 1u, LXY = LX * (eJ == 1 ? (uint32_t)(NYl - 1) : 1u);
+      const uint32_t offIJ = (eI == 1 ? (uint32_t)(I - 1) : 0u) + LX * (eJ == 1 ? (uint32_t)(J - 1) : 0u);
+      const int entIJ = eI + 3 * eJ;
+#pragma unroll
+      for (int k = 0; k < n; ++k) {
+        const int K = K0 + k, eK = K == 0 ? 0 : K == NZl ? 2 : 1;
+        const uint32_t off = offIJ + (eK == 1 ? LXY * (uint32_t)(K - 1) : 0u);
+        const int ent = entIJ + 9 * eK;
+        r.ps[k] = (uint16_t)(lt[ent] + off);
+        if constexpr (STAGE) r.u[k] = staged[r.ps[k]];
+        else {
+          const uint32_t dof = lt[27 + ent] + off;
+          r.u[k] = (ABL & 4) ? 1e-9 * dof : a.src[dof];
+        }
+      }
+      return;
+    }
+    (void)lt; (void)a_; (void)b_;
 #pragma unroll
     for (int k = 0; k < n; ++k) {
       const uint32_t e = r.ps[k], run = e >> BLOCK_PACK_OFF_BITS, off = e & ((1u << BLOCK_PACK_OFF_BITS) - 1u);
@@ -1798,6 +1834,10 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
   constexpr bool STAGE = BP::STAGE;
   double *const staged = acc + bp.max_list; // STAGE: src values of the current brick, indexed like acc
   uint32_t *const run_tab = reinterpret_cast<uint32_t *>(acc + (STAGE ? 2 : 1) * (size_t)bp.max_list);
+  // lattice tables of the current / next block behind the two run tables (block parity, parked like them)
+  uint32_t *const lat_tab = run_tab + 4 * BLOCK_MAX_RUNS;
+  constexpr bool use_lattice = BP::LATT;
+  uint32_t lat_word = 0;
   uint32_t r0 = RUNS ? bp.run_off[pb] : 0u;
   int n_runs = RUNS ? (int)(bp.run_off[pb + 1] - r0) : 0;
   uint32_t run_slot = 0, run_dof = 0;
@@ -1844,18 +1884,19 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
   B.ent = entry(gp + 1);
   BP::issue_loads(a, bp, A, abm, lane_ok, true);
   if constexpr (BP::PACK) {
-    // the first block's run table must be in LDS before the first decode
+    // the first block's run table (and lattice table) must be in LDS before the first decode
     uint32_t *const rt0 = run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS);
     if (t < n_runs) {
       rt0[t] = bp.runs[2 * (r0 + t)];
       rt0[BLOCK_MAX_RUNS + t] = bp.runs[2 * (r0 + t) + 1];
     }
+    if constexpr (use_lattice) { if (t < BLOCK_LATTICE_WORDS) lat_tab[(b & 1u) * BLOCK_LATTICE_WORDS + t] = bp.lattice[(uint64_t)pb * BLOCK_LATTICE_WORDS + t]; }
     __syncthreads();
     if constexpr (STAGE) {
       enter_block(rt0, n_runs, m);
       __syncthreads();
     }
-    BP::decode_and_gather(a, A, rt0, staged);
+    BP::decode_and_gather(a, A, rt0, staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_);
   } else
     BP::issue_gather(a, A);
 
@@ -1879,6 +1920,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
         nx_r0 = bp.run_off[p1];
         nx_r1 = bp.run_off[p1 + 1];
       }
+      if constexpr (use_lattice) { if (t < BLOCK_LATTICE_WORDS) lat_word = bp.lattice[(uint64_t)p1 * BLOCK_LATTICE_WORDS + t]; }
     }
     if (gp + 1 == boundary) {
       if constexpr (BP::PACK) {
@@ -1974,6 +2016,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
             rn[t] = run_slot;
             rn[BLOCK_MAX_RUNS + t] = run_dof;
           }
+          if constexpr (use_lattice) { if (t < BLOCK_LATTICE_WORDS) lat_tab[((b + 1) & 1u) * BLOCK_LATTICE_WORDS + t] = lat_word; }
         }
       } else if constexpr (RUNS) {
         if (t < n_runs) {
@@ -2088,7 +2131,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
     finish_pass();
     BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
-    if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged); // b: block of the next pass
+    if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); // b: block of the next pass
     A.ent = entA2;
     prefetch_list();
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
@@ -2096,7 +2139,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
     BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0]);
     finish_pass();
     BP5_STAMP(6)
-    if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged); }
+    if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); }
     B.ent = entB2;
   }
   if constexpr (DOTS) {

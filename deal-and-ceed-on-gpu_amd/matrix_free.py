@@ -161,6 +161,12 @@ class MatrixFree:
         _lib.check(_lib.lib().bp5_mf_block_plan_info(self.handle, C.byref(nb), C.byref(mr), C.byref(pk)))
         return nb.value, mr.value, bool(pk.value)
 
+    def block_plan_lattice(self):
+        """number of the block plan's LATTICE blocks (closed-form indices: no per-DoF index stream)"""
+        n = C.c_uint32()
+        _lib.check(_lib.lib().bp5_mf_block_plan_lattice(self.handle, C.byref(n)))
+        return n.value
+
     def get_apply_variant(self):
         """The kernel variant a whole-range application resolves to (what 0 = default means here)."""
         v = C.c_int()

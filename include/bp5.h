@@ -254,6 +254,11 @@ int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups);
  * block, and whether the packed one-u16-per-DoF index form is available (<= 128 runs per block; brick-major numbering
  * gives ~30, a slab's boundary bricks with their ghost rows ~70) -- every rank of a multi-GPU run should report 1 */
 int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, int *packed_indices);
+/* ... and how many of its cell blocks are LATTICE blocks: full boxes of cells whose DoFs are numbered entity by entity (what a brick-major
+ * numbering produces; recognised topologically and verified entry by entry when the plan is built).  For those the kernel computes every
+ * entry's list slot and DoF in closed form from the cell's position in its block and reads no per-DoF index at all (the packed stream of
+ * the other blocks costs 2 bytes per cell-local DoF); the results are bitwise the same either way. */
+int bp5_mf_block_plan_lattice(bp5_mf *mf, uint32_t *n_lattice_blocks);
 /* the variant a whole-range application resolves to (what "0" means for this handle) */
 int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
 

@@ -367,6 +367,55 @@ def test_deterministic_block_kernel_for_the_other_degrees(p, cells, block, quad)
     assert float((sols[0] - sols[1]).abs().max()) < 1e-11 * float(sols[1].abs().max())   # (only the summation order differs)
 
 
+@pytest.mark.parametrize("p,cells,block,kw", [(4, (9, 8, 6), (4, 4, 4), {}), (4, (8, 8, 12), (4, 4, 2), dict(rank=1, n_ranks=2)), (4, (8, 8, 13), (4, 4, 4), dict(rank=1, n_ranks=3)),
+                                            (1, (17, 9, 10), (8, 8, 8), {}), (2, (9, 8, 5), (8, 8, 4), {}), (3, (9, 5, 6), (8, 4, 4), dict(rank=1, n_ranks=2)),
+                                            (5, (7, 5, 3), (6, 4, 2), {}), (6, (5, 4, 3), (4, 4, 2), {}), (7, (5, 3, 3), (4, 2, 2), {}), (8, (3, 3, 3), (2, 2, 2), {})])
+def test_lattice_blocks_need_no_index_stream(p, cells, block, kw):
+    """Structured bricks with brick-major numbering (the library's own generator; partial bricks at the mesh edges; the ghost-touching layer
+    of a slab with its block-major ghost plane): every block is recognised as a LATTICE block (topologically, then verified entry by entry on
+    the host), and the kernel build that computes list slots and DoFs in closed form -- no per-DoF index stream -- gives bitwise the result
+    of the packed-index build (BP5_LATTICE_INDICES=0) and matches the atomic pencil kernel."""
+    torch = _t()
+    mesh = pkg.BrickMesh(p, cells, h=0.2, deform_amp=0.03, cell_block=block, dof_numbering=1, cell_block_order=1, **kw)
+    ops = []
+    for lattice in ("1", "0"):
+        os.environ["BP5_LATTICE_INDICES"] = lattice                 # read when the block plan is built
+        op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+        op.mf_data.set_apply_variant(56)
+        op.mf_data.set_block_workgroups(8)
+        nb, _, packed = op.mf_data.block_plan_info()
+        assert packed and op.mf_data.block_plan_lattice() == (nb if lattice == "1" else 0)
+        ops.append(op)
+    del os.environ["BP5_LATTICE_INDICES"]
+    n = mesh.n_owned + mesh.n_ghost
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    src = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
+    outs, names = [], []
+    b = ops[0].assemble_rhs()                                  # (one right-hand side for both: its assembly scatters with atomics)
+    for op in ops:
+        d = op.initialize_dof_vector()
+        d.fill_(float("nan"))
+        pkg.lib().bp5_apply(op.mf_data.handle, _cptr(op.coef), _cptr(src), _cptr(d), 1)    # (single-rank entry point: ghosts are plain entries here)
+        outs.append(d)
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(5, 0.0)
+        pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix()) if not kw else None
+        names.append(ctl.apply_kernel)
+        outs.append(x)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    if not kw:
+        assert int(names[0].split(",")[-1].rstrip(">")) & 16777216 and not int(names[1].split(",")[-1].rstrip(">")) & 16777216
+    ops[0].mf_data.set_apply_variant(1 if p in (1, 3) else 0 if p != 4 else 3)
+    ref = ops[0].initialize_dof_vector()
+    pkg.lib().bp5_apply(ops[0].mf_data.handle, _cptr(ops[0].coef), _cptr(src), _cptr(ref), 1)
+    assert float((ref - outs[0]).abs().max()) < 1e-12 * float(ref.abs().max())
+
+
+def _cptr(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr())
+
+
 @pytest.mark.parametrize("quad", [0, 1])
 def test_block_kernel_on_block_aligned_cell_ranges(quad):
     """bp5_apply_cells with the block kernel on cell ranges that are unions of whole bricks (what a host that
