@@ -1792,8 +1792,8 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
         uint32_t n_cols = 0;
         BP5_TRY(vmult(d, h, g, &n_cols));
         BP5_TRY(phase_mark(mf, 4));
-        if (one_launch) hipLaunchKernelGGL(cgm_finalize4_kernel<true>, dim3(1), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc, mf->d_st);
-        else hipLaunchKernelGGL(cgm_finalize4_kernel<false>, dim3(1), dim3(VB), 0, s, mf->d_partials, (int)n_cols, mf->d_sc, mf->d_st);
+        if (one_launch) hipLaunchKernelGGL(cgm_finalize4_kernel<true>, dim3(1), dim3(FIN4_THREADS), 0, s, mf->d_partials, (int)n_cols, mf->d_sc, mf->d_st);
+        else hipLaunchKernelGGL(cgm_finalize4_kernel<false>, dim3(1), dim3(FIN4_THREADS), 0, s, mf->d_partials, (int)n_cols, mf->d_sc, mf->d_st);
       } else {
         BP5_TRY(folded_vmult(d, h)); // (h: zeroed by cgm_init_kernel before the first, by the update kernel before every later application)
         BP5_TRY(phase_mark(mf, 4));

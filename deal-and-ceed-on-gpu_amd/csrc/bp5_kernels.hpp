@@ -3069,9 +3069,9 @@ static __global__ void __launch_bounds__(VB) cgm_dots_kernel(const double *p, co
 }
 // scalars of one merged iteration (solver.h:496-506,533)
 static __global__ void cgm_control_kernel(double *sc, int *st);
-// Fused iteration (D == 1: rows 4-6 of the partial sums mirror rows 2, 1, 3): ONE workgroup sums the four distinct rows in the fixed tree
-// order of finalize_kernel (same bits) and -- on one rank, where no all-reduce sits in between -- takes the scalar step right away: one
-// launch instead of two (the earlier one-launch probe used seven workgroups and a device-scope fence, which cost more than it saved)
+// Fused iteration (D == 1: rows 4-6 of the partial sums mirror rows 2, 1, 3): ONE workgroup sums the four distinct rows in a fixed order
+// and -- on one rank, where no all-reduce sits in between -- takes the scalar step right away: one launch instead of two (the earlier
+// one-launch probe used seven workgroups and a device-scope fence, which cost more than it saved)
 __device__ __forceinline__ void cgm_control_step(double *sc, int *st)
 {
   if (st[ST_DONE]) { st[ST_PENDING] = 0; return; }
@@ -3088,33 +3088,44 @@ __device__ __forceinline__ void cgm_control_step(double *sc, int *st)
   if (res <= sc[SC_TOL] || it >= st[ST_MAXIT]) { st[ST_DONE] = 1; st[ST_PENDING] = 1; return; }
   sc[SC_BETA] = alpha * (R[4] + alpha * R[5]) / R[6];
 }
+constexpr int FIN4_THREADS = 1024; // sixteen waves: four per row
 template <bool CONTROL>
-__global__ void __launch_bounds__(VB) cgm_finalize4_kernel(const double *partials, int nblk, double *sc, int *st)
+__global__ void __launch_bounds__(FIN4_THREADS) cgm_finalize4_kernel(const double *partials, int nblk, double *sc, int *st)
 {
   if (st[ST_DONE]) { // frozen solve: nothing to sum; the scalar step still clears the pending flag
     if (CONTROL && threadIdx.x == 0) cgm_control_step(sc, st);
     return;
   }
-  __shared__ double red[VB];
-  double *out = sc + SC_R0;
-  for (int k = 0; k < 4; ++k) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += VB) s += partials[k * PARTIAL_STRIDE + i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = VB / 2; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      out[k] = red[0];
-      if (k == 1) out[5] = red[0]; // v.Dv = v.v
-      if (k == 2) out[4] = red[0]; // r.Dv = r.v
-      if (k == 3) out[6] = red[0]; // r.Dr = r.r
-    }
-    __syncthreads();
+  // 256 lanes per row, four independent loads per lane and trip (a lane that sums its columns one dependent load after the other pays a memory
+  // latency per column: 22-27 us per launch on the 54^3 problem, more than the two launches this kernel replaced); fixed order: lane-strided
+  // partial sums, shuffle tree per wave, the four waves of a row in ascending order
+  __shared__ double red[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = wave >> 2, l = ((wave & 3) << 6) | lane; // row, lane within the row (0..255)
+  const double *row = partials + k * PARTIAL_STRIDE;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int i = l; i < nblk; i += 1024) {
+    const double a0 = row[i], a1 = i + 256 < nblk ? row[i + 256] : 0.0, a2 = i + 512 < nblk ? row[i + 512] : 0.0, a3 = i + 768 < nblk ? row[i + 768] : 0.0;
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
   }
-  if (CONTROL && threadIdx.x == 0) cgm_control_step(sc, st);
+  double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  double *out = sc + SC_R0;
+  if (threadIdx.x < 4) {
+    const int r = threadIdx.x;
+    const double t = (red[4 * r] + red[4 * r + 1]) + (red[4 * r + 2] + red[4 * r + 3]);
+    out[r] = t;
+    if (r == 1) out[5] = t; // v.Dv = v.v
+    if (r == 2) out[4] = t; // r.Dv = r.v
+    if (r == 3) out[6] = t; // r.Dr = r.r
+  }
+  if constexpr (CONTROL) {
+    __syncthreads(); // (workgroup scope: the four sums are visible to thread 0)
+    if (threadIdx.x == 0) cgm_control_step(sc, st);
+  }
 }
 
 static __global__ void cgm_control_kernel(double *sc, int *st) { cgm_control_step(sc, st); }
