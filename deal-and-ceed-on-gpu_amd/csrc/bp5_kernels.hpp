@@ -2575,6 +2575,37 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
     } else if (ADD) dst[g] += s;
     else dst[g] = s;
   };
+  // the partials of one ordinal (offset j in its run), summed in ascending group order: the first four slot bases are loaded together, then
+  // the four partials together -- two memory latencies instead of two per contributing group (faces have 2 groups, edges 4, corners 8)
+  auto sum1 = [&](uint32_t b, uint32_t e, uint32_t j) -> double {
+    if (b >= e) return 0.0; // (a DoF no cell touches has no slot: its sum is zero)
+    const uint32_t nq = e - b;
+    const uint32_t s0 = cr.slots[b], s1 = nq > 1 ? cr.slots[b + 1] : 0u, s2 = nq > 2 ? cr.slots[b + 2] : 0u, s3 = nq > 3 ? cr.slots[b + 3] : 0u;
+    const double p0 = partial[s0 + j], p1 = nq > 1 ? partial[s1 + j] : 0.0, p2 = nq > 2 ? partial[s2 + j] : 0.0, p3 = nq > 3 ? partial[s3 + j] : 0.0;
+    double sum = p0;
+    if (nq > 1) sum += p1;
+    if (nq > 2) sum += p2;
+    if (nq > 3) sum += p3;
+    for (uint32_t q = b + 4; q < e; ++q) sum += partial[cr.slots[q] + j];
+    return sum;
+  };
+  auto sum2 = [&](uint32_t b, uint32_t e, uint32_t j) -> bp5_d2u { // two consecutive ordinals of one run: 16-byte loads
+    if (b >= e) return bp5_d2u{0.0, 0.0};
+    const uint32_t nq = e - b;
+    const uint32_t s0 = cr.slots[b], s1 = nq > 1 ? cr.slots[b + 1] : 0u, s2 = nq > 2 ? cr.slots[b + 2] : 0u, s3 = nq > 3 ? cr.slots[b + 3] : 0u;
+    const bp5_d2u z{0.0, 0.0};
+    const bp5_d2u p0 = *reinterpret_cast<const bp5_d2u *>(partial + s0 + j), p1 = nq > 1 ? *reinterpret_cast<const bp5_d2u *>(partial + s1 + j) : z,
+                  p2 = nq > 2 ? *reinterpret_cast<const bp5_d2u *>(partial + s2 + j) : z, p3 = nq > 3 ? *reinterpret_cast<const bp5_d2u *>(partial + s3 + j) : z;
+    bp5_d2u sum = p0;
+    if (nq > 1) { sum.x += p1.x; sum.y += p1.y; }
+    if (nq > 2) { sum.x += p2.x; sum.y += p2.y; }
+    if (nq > 3) { sum.x += p3.x; sum.y += p3.y; }
+    for (uint32_t q = b + 4; q < e; ++q) {
+      const bp5_d2u t2 = *reinterpret_cast<const bp5_d2u *>(partial + cr.slots[q] + j);
+      sum.x += t2.x; sum.y += t2.y;
+    }
+    return sum;
+  };
   for (uint32_t tile = cr.tile0 + blockIdx.x; tile < (DOTS ? cr.tile0 + cr.n_tiles : cr.tile0 + blockIdx.x + 1); tile += gridDim.x) {
     if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
     const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= COMBINE_TILE
@@ -2596,12 +2627,7 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
           if (s_start[mid] <= i) lo = mid; else hi = mid;
         }
         const uint32_t j = i - s_start[lo], b = s_soff[lo], e = s_soff[lo + 1];
-        double sum = 0.0; // (a DoF no cell touches has no slot: its sum is zero)
-        if (b < e) {
-          sum = partial[cr.slots[b] + j];
-          for (uint32_t q = b + 1; q < e; ++q) sum += partial[cr.slots[q] + j];
-        }
-        finish((s_dof0[lo] & 0x7fffffffu) + j, (s_dof0[lo] & 0x80000000u) != 0, sum);
+        finish((s_dof0[lo] & 0x7fffffffu) + j, (s_dof0[lo] & 0x80000000u) != 0, sum1(b, e, j));
       }
       continue;
     }
@@ -2617,31 +2643,14 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
     const bool dir = (s_dof0[lo] & 0x80000000u) != 0;
     if (i + 1 < cr.n_shared && i + 1 < s_start[lo + 1]) {
       // both ordinals in one run: their partials are neighbours in every contributing group's slab range -> 16-byte loads
-      bp5_d2u s2 = bp5_d2u{0.0, 0.0}; // (a DoF no cell touches has no slot: its sum is zero)
-      if (b < e) {
-        s2 = *reinterpret_cast<const bp5_d2u *>(partial + cr.slots[b] + j);
-        for (uint32_t q = b + 1; q < e; ++q) {
-          const bp5_d2u t2 = *reinterpret_cast<const bp5_d2u *>(partial + cr.slots[q] + j);
-          s2.x += t2.x; s2.y += t2.y;
-        }
-      }
+      const bp5_d2u s2 = sum2(b, e, j);
       finish(g, dir, s2.x);
       finish(g + 1, dir, s2.y);
     } else {
-      double s = 0.0;
-      if (b < e) {
-        s = partial[cr.slots[b] + j];
-        for (uint32_t q = b + 1; q < e; ++q) s += partial[cr.slots[q] + j];
-      }
-      finish(g, dir, s);
+      finish(g, dir, sum1(b, e, j));
       if (i + 1 < cr.n_shared) { // first ordinal of the next run
         const uint32_t l2 = lo + 1, b2 = s_soff[l2], e2 = s_soff[l2 + 1];
-        double s1 = 0.0;
-        if (b2 < e2) {
-          s1 = partial[cr.slots[b2]];
-          for (uint32_t q = b2 + 1; q < e2; ++q) s1 += partial[cr.slots[q]];
-        }
-        finish(s_dof0[l2] & 0x7fffffffu, (s_dof0[l2] & 0x80000000u) != 0, s1);
+        finish(s_dof0[l2] & 0x7fffffffu, (s_dof0[l2] & 0x80000000u) != 0, sum1(b2, e2, 0u));
       }
     }
   }
