@@ -931,7 +931,7 @@ static int launch_diagonal(bp5_mf *mf, const double *coef, double *diag)
   const bool affine = mf->geometry_mode == BP5_GEOM_AFFINE;
   hipLaunchKernelGGL(diagonal_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, affine ? mf->d_scalar_plane : coef,
                      affine ? (uint64_t)mf->n_cells * mf->n3 : mf->coef_plane_stride, mf->coef_cell_stride, affine ? mf->d_gcell : (const double *)nullptr, mf->d_tab, mf->n_cells, diag,
-                     mf->has_hanging ? (const uint32_t *)mf->d_hang_mask : (const uint32_t *)nullptr);
+                     mf->has_hanging ? (const uint32_t *)mf->d_hang_mask : (const uint32_t *)nullptr, mf->n_planes());
   KERNEL_CHECK();
   if (mf->has_hanging) { // the coarse DoFs named on constrained faces / edges: one cell-operator application per such entry
     hipLaunchKernelGGL(diagonal_hanging_kernel<n>, dim3(grid), dim3(n, n, n), 0, mf->stream, mf->d_l2g, affine ? mf->d_scalar_plane : coef,
@@ -946,7 +946,6 @@ extern "C" int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag
 {
   if (!mf || (!coef && mf->geometry_mode != BP5_GEOM_AFFINE) || !diag) return fail(BP5_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(mf->device));
-  if (mf->operator_kind == BP5_OP_HELMHOLTZ) return fail(BP5_ERR_UNSUPPORTED, "bp5_compute_diagonal: Poisson operator only");
   HIP_TRY(hipMemsetAsync(diag, 0, mf->n_local() * sizeof(double), mf->stream));
   if (mf->n_cells) BP5_TRY(diagonal_dispatch(mf, coef, diag));
   if (mf->comm && !mf->neighbors.empty()) { // ghost contributions to their owners

@@ -2389,7 +2389,7 @@ __global__ void __launch_bounds__(n *n *n) rhs_kernel(const uint32_t *l2g, const
 // mode (gcell != NULL), the scalar plane times the cell's constant K K^T.
 template <int n>
 __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, const double *coef, uint64_t plane_stride, uint64_t cell_stride, const double *gcell,
-                                                          const double *tab, uint32_t n_cells, double *diag, const uint32_t *hang_mask)
+                                                          const double *tab, uint32_t n_cells, double *diag, const uint32_t *hang_mask, int n_planes = 6)
 {
   constexpr int n2 = n * n, n3 = n2 * n;
   __shared__ double S[n3], t1[n3], t2[n3], NN[n2], DD[n2], ND[n2];
@@ -2404,7 +2404,7 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
   __syncthreads();
   for (uint64_t cell = blockIdx.x; cell < n_cells; cell += gridDim.x) {
     double acc = 0.0;
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < n_planes; ++c) { // (n_planes == 7: the Helmholtz operator's mass plane a JxW with the factors N*N in every direction)
       // this thread's q-point (a,b,c) = (i,j,k) in the device (pair) layout
       const uint64_t at = cell * (gcell ? (uint64_t)n3 : cell_stride) + coef_off<n>(i, j + n * k);
       S[q] = gcell ? coef[at] * gcell[(uint64_t)c * n_cells + cell] : coef[(uint64_t)c * plane_stride + at];
@@ -2413,7 +2413,7 @@ __global__ void __launch_bounds__(n *n *n) diagonal_kernel(const uint32_t *l2g, 
       const double *Y = (c == 1) ? DD : (c == 3 || c == 5) ? ND : NN;
       const double *Z = (c == 2) ? DD : (c == 4 || c == 5) ? ND : NN;
       const double y = Cell3<n>::template tensor3<true>(X, Y, Z, S, t1, t2, i, j, k);
-      acc += (c < 3) ? y : 2.0 * y;
+      acc += (c < 3 || c == 6) ? y : 2.0 * y;
     }
     // entries on constrained faces / edges stand for coarse DoFs: diagonal_hanging_kernel computes theirs
     const uint32_t hm = hang_mask ? hang_mask[cell] : 0u;

@@ -266,7 +266,7 @@ int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
  * Jacobi preconditioner for the `diag` slot every solver kernel of the reference already threads through
  * (bp5/solver.h:68,100,131,170; bp5/step-64.cu:428-432 fills it with ones).  Setup-time, matrix-free
  * (sum-factorised, no element matrices); ghost contributions are sent to their owners when a communicator is set.
- * diag: owned + ghost storage, ghost entries are left zero. */
+ * diag: owned + ghost storage, ghost entries are left zero.  BP5_OP_HELMHOLTZ: the mass term is included. */
 int bp5_compute_diagonal(bp5_mf *mf, const double *coef, double *diag, int invert);
 
 /* b_i = int phi_i with Gauss(p+1), constrained rows 0 (assemble_rhs, bp5/step-64.cu:372-418) */

@@ -91,6 +91,20 @@ def main():
         pkg.SolverCGFullMerge(pkg.IterationNumberControl(iters, 0.0)).solve(op, xj, b, pkg.DiagonalMatrix(inv_diag))
         res["x_jacobi"] = xj[:no].cpu().numpy()
         res["l2"] = np.asarray(op.l2_norm_solution(x))       # ghosts of x refreshed inside (bp5_l2_norm_solution)
+        # step-64's Helmholtz operator on the native kernel across the ranks (same mesh, same halo plan): operator and merged CG
+        hop = pkg.HelmholtzOperator(mesh, pkg.QUAD_GAUSS, pkg.COEF_STEP64, comm=comm)
+        hop.mf_data.set_apply_variant(56 if variant == 56 else 0)
+        hdst = hop.initialize_dof_vector()
+        hdst.fill_(float("nan"))
+        hop.vmult(hdst, src.clone())
+        res["Ah"] = hdst[:no].cpu().numpy()
+        xh = hop.initialize_dof_vector()
+        hctl = pkg.IterationNumberControl(iters, 0.0)
+        pkg.SolverCGFullMerge(hctl).solve(hop, xh, b, pkg.DiagonalMatrix())
+        res["x_helmholtz"] = xh[:no].cpu().numpy()
+        res["fused_helmholtz"] = np.asarray(bool(hctl.dot_products_fused))
+        hop.mf_data.synchronize()
+        hop.mf_data.close()
         np.savez(os.path.join(out, f"rank{rank}.npz"), **res)
         op.mf_data.synchronize()
         op.mf_data.close()

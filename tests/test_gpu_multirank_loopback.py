@@ -124,6 +124,19 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
     l2 = O.l2_norm_solution(pr.mesh, full["x_merged_default"])
     for z in ranks:
         assert abs(float(z["l2"]) - l2) < 1e-12 * l2
+    # step-64's Helmholtz operator (native kernel) across the ranks: operator and merged CG against the oracle on the undivided mesh
+    c = pr.mesh.constrained.astype(np.int64)
+
+    def Ah(s):
+        d = O.apply_helmholtz_cells(pr.mesh, pr.N, pr.D, pr.w, s)
+        d[c] = s[c]
+        return d
+
+    assert _rel(full["Ah"], Ah(O.deterministic_src(nd, seed=21))) < 1e-13
+    xh, _, _ = O.cg_merged(Ah, b_ref, iters)
+    assert _rel(full["x_helmholtz"], xh) < 1e-11
+    for z in ranks:
+        assert bool(z["fused_helmholtz"]) == on_block_kernel
 
 
 def test_bench_with_two_ranks_as_the_driver_launches_it():
