@@ -31,6 +31,11 @@ def _check(line, steps, warmup):
     assert f"{d['config']['dofs_per_gpu']} DoFs" in c["sample"]          # the CPU leg runs on the bench's own mesh
     s = d["sustained"]
     assert s["unit"] == "DoF/s" and s["value"] > 0 and s["iterations"] >= 1 and s["repetitions"] >= 1
+    # round 3: the kernel name comes from the solve itself, the whole-iteration figure says what it is based on, the moved-bytes fractions
+    # stand beside the contract figures, the host set-up time is reported
+    assert r["kernel"].startswith("apply_") and 0 < r["frac_moved"] <= r["frac"] + 1e-12 and r["bytes_moved_per_dof"] <= r["bytes_per_dof"]
+    assert "contract formula" in d["roofline_cg"]["basis"] and d["roofline_cg"]["frac_moved_of_hbm_peak"] <= d["roofline_cg"]["frac_of_hbm_peak"]
+    assert d["host_setup_s"] > 0 and d["config"]["exchange_schedule"] == "none (one rank)"
     return d
 
 
@@ -59,6 +64,21 @@ def test_bench_quotes_the_committed_pmc_passes_when_the_live_ones_are_switched_o
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None      # (no committed passes for this small workload)
+
+
+def test_bench_baseline_config_aliases():
+    """`--config N`: every BASELINE.json configuration as one flag (1: p = 2, 8^3 cells, 10 iterations -- the plumbing case, run here; 2: 54^3; 4: the degree
+    sweep; 5: p = 6 deformed -- checked through --dry-run on the host: sizes only)."""
+    r = subprocess.run([sys.executable, BENCH, "--config", "1", "--no-cpu-baseline", "--no-traffic-pass", "--sustained-iters", "0"], capture_output=True,
+                       text=True, timeout=600, cwd=bp5_pkg.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["steps"] == 10 and d["config"]["baseline_config"] == 1 and "p=2" in d["config"]["workload"] and "8x8x8 hex cells, 4913 DoFs" in d["config"]["workload"]
+    for cfg, want in ((2, (54, 54, 54, 10218313)), (5, (61, 61, 61, 49430863))):
+        r = subprocess.run([sys.executable, BENCH, "--config", str(cfg), "--dry-run"], capture_output=True, text=True, timeout=600, cwd=bp5_pkg.ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert tuple(d["cells"]) == want[:3] and d["n_global_dofs"] == want[3]
 
 
 def test_bench_under_the_distributed_launcher_one_rank():
