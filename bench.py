@@ -435,8 +435,15 @@ def main():
         achieved = B_kernel * n_dofs_local / apply_s / 1e9 if apply_s > 0 else 0.0
         # what the launched kernel has to move for its own representation (block kernel: one packed u16 per cell-local DoF instead of the
         # 4r of local_to_global; fused: r at the stored DoFs only -- p.v comes from the quadrature-point energy, v.v from LDS)
-        B_moved = (16.0 + 2.0 * r + G * 8.0 * r + (8.0 if fused else 0.0)) if block_kernel else B_kernel
         kname = ctl.apply_kernel or f"apply variant {ev}"     # reported by the solve: the kernel it launched, as a profiler prints it
+        # index bytes the block kernel reads: one packed u16 per cell-local DoF, or -- lattice build (kernel id bit 16777216): closed-form
+        # indices -- one u32 per CELL
+        try:
+            lattice_kernel = bool(int(kname.split(",")[-1].rstrip(">")) & 16777216)
+        except ValueError:
+            lattice_kernel = False
+        idx_moved = 4.0 * r / (p + 1) ** 3 if lattice_kernel else 2.0 * r
+        B_moved = (16.0 + idx_moved + G * 8.0 * r + (8.0 if fused else 0.0)) if block_kernel else B_kernel
         tr = None
         if world == 1 and not args.no_traffic_pass and not args.rehearsal:
             wl = ["--operator", args.operator, "--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
@@ -496,9 +503,11 @@ def main():
                          "algorithmic_formula": (f"16 + I*4r + G*8r" + (" + 24 [fused dot products: p, r, v]" if fused else "") +
                                                  f" B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)"),
                          # what this kernel has to move for its own representation (the contract formula credits I = 1 and 24 B for the dots)
-                         "bytes_moved_formula": ((f"16 + 2r + G*8r" + (" + 8 [r at the stored DoFs; p.v comes from the quadrature-point energy, v.v from LDS]" if fused else "") +
-                                                  f" = {B_moved:.1f} B/DoF: one packed u16 (run, offset) per cell-local DoF "
-                                                  f"instead of the 4r of local_to_global") if block_kernel else
+                         "bytes_moved_formula": ((("16 + 4r/(p+1)^3 + G*8r" if lattice_kernel else "16 + 2r + G*8r") +
+                                                  (" + 8 [r at the stored DoFs; p.v comes from the quadrature-point energy, v.v from LDS]" if fused else "") +
+                                                  f" = {B_moved:.1f} B/DoF: " + ("lattice blocks, one u32 per CELL (closed-form indices) " if lattice_kernel else
+                                                                                "one packed u16 (run, offset) per cell-local DoF ") +
+                                                  "instead of the 4r of local_to_global") if block_kernel else
                                                  f"16 + 4r + G*8r = {B_op:.1f} B/DoF (local_to_global is read)")},
         }
         if args.rehearsal:

@@ -265,6 +265,12 @@ extern "C" int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups)
   mf->block_max_wg = max_workgroups;
   return BP5_OK;
 }
+extern "C" int bp5_mf_set_streaming(bp5_mf *mf, int policy)
+{
+  if (!mf || policy < -1 || policy > 1) return fail(BP5_ERR_INVALID, "bad argument");
+  mf->streaming = policy;
+  return BP5_OK;
+}
 extern "C" int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, int *packed_indices)
 {
   if (!mf || !n_blocks || !max_runs || !packed_indices) return fail(BP5_ERR_INVALID, "null argument");
@@ -1749,6 +1755,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     // BP5_UPDATE_UNROLL = 1 | 2 | 4; profiles/r2: 1.03 / 1.00 / 0.99 ms per iteration at 1e8 DoFs; default 4)
     static const int unroll = [] { const char *e = getenv("BP5_UPDATE_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 1 || u == 2) ? u : 4; }();
     const int gridu = stream_grid(n, 2 * unroll);
+    const bool streaming = streaming_accesses(mf);
     auto launch_update = [&](int mode) {
       if (prezero && mode != 0) {
         if (mode == 1) hipLaunchKernelGGL((cgm_update_kernel<1, 4, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
@@ -1756,6 +1763,11 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
         return;
       }
 #define BP5_UPD(M, U) hipLaunchKernelGGL((cgm_update_kernel<M, U>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st)
+      if (streaming && unroll == 4 && mode != 0) { // (profiles/r3/README.md, x_*: -2 ... -3 % per iteration up to 2e7 DoFs, +1 % at 1e8)
+        if (mode == 1) hipLaunchKernelGGL((cgm_update_kernel<1, 4, false, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+        else hipLaunchKernelGGL((cgm_update_kernel<2, 4, false, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
+        return;
+      }
       if (unroll == 1) { if (mode == 0) BP5_UPD(0, 1); else if (mode == 1) BP5_UPD(1, 1); else BP5_UPD(2, 1); }
       else if (unroll == 4) { if (mode == 0) BP5_UPD(0, 4); else if (mode == 1) BP5_UPD(1, 4); else BP5_UPD(2, 4); }
       else { if (mode == 0) BP5_UPD(0, 2); else if (mode == 1) BP5_UPD(1, 2); else BP5_UPD(2, 2); }

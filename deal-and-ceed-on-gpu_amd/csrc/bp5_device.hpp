@@ -46,6 +46,7 @@ struct bp5_event {
   hipEvent_t ev = nullptr;
 };
 
+constexpr size_t STREAMING_MAX_DOFS = 24000000; // see bp5_mf_set_streaming (include/bp5.h)
 struct bp5_mf {
   int degree = 0, quadrature = 0, coefficient = 0, n = 0, n3 = 0, device = 0;
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
@@ -55,6 +56,7 @@ struct bp5_mf {
   uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
   bool combine_csr = false; // A/B: per-DoF CSR combine kernel instead of the run-length one
   int block_max_wg = 0; // 0: persistent grid sized from the CU count; > 0: cap (tests force several blocks per workgroup)
+  int streaming = -1; // bp5_mf_set_streaming: -1 chosen by size, 0 ordinary accesses, 1 non-temporal accesses to once-used data
   int auto_team = -1;  // -1 not decided; 1: the x-row team plan could be built (p = 1, 3 default)
   int auto_block = -1; // -1 not decided; 1: the caller's cell blocks fit three block-kernel workgroups per CU
   double *d_scalar_plane = nullptr, *d_gcell = nullptr;
@@ -197,6 +199,10 @@ enum { COMBINE_ALL = 0, COMBINE_GHOST = 1, COMBINE_OWNED = 2 };
 int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window = COMBINE_ALL);
 // [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
 bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1);
+// Non-temporal accesses to the data a CG iteration touches once (the operator's metric planes; v and x in the update kernel) keep it from evicting
+// the vectors that ARE reused (p, r) from the 256 MB memory-side cache: a gain while those fit there (-6 % per iteration at 1e7 DoFs), a small loss
+// beyond (+1 % at 1e8; profiles/r3/README.md, x_*)
+inline bool streaming_accesses(const bp5_mf *mf) { return mf->streaming >= 0 ? mf->streaming != 0 : mf->n_local() <= STREAMING_MAX_DOFS; }
 
 // ------------------------------------------------------------------------------------ operator launches
 // 1-D tables as the kernels read them: the (anti)symmetric half of N and D (p <= 4), or their even-odd split (mv_even_odd)
@@ -789,14 +795,17 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
         }
         constexpr int LATT = 16777216; // every block a lattice block: closed-form indices, no per-DoF index stream
         const bool lattice = variant == 56 && dp_->packed && dp_->lattice && dp_->n_lattice_blocks == dp_->n_groups;
+        const bool ntm = streaming_accesses(mf); // non-temporal metric loads
         if (mf->fuse.on) { // the solver asked for the fused dot products (only ever with the packed default shape)
           if (!dp_->packed || variant != 56) return fail(BP5_ERR_INVALID, "fused dot products need the packed block kernel");
+          if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT + 32768>(mf, coef, src, dst, overwrite);
           if (lattice)
             return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite)
                         : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite);
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite);
         }
+        if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT + 32768>(mf, coef, src, dst, overwrite);
         if (lattice)
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite);

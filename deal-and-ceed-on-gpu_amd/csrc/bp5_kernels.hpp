@@ -2973,7 +2973,9 @@ __device__ __forceinline__ void cgm_update_one(double &p, double &r, const doubl
 // ZV: v is consumed here for the last time before the next operator application overwrites it -- an operator kernel that accumulates
 // with atomics needs it zeroed, and this kernel holds v's values in registers anyway: it stores the zeros itself (one zero-fill
 // launch -- two fill kernels in the runtime -- less per iteration)
-template <int MODE, int U = 2, bool ZV = false>
+// NTX: v (consumed here for the last time) and x (touched by nothing else) go past the caches with non-temporal accesses, so that on a mesh whose
+// vectors fit the 256 MB memory-side cache p and r are still there when the operator kernel gathers them (bp5_mf_set_streaming)
+template <int MODE, int U = 2, bool ZV = false, bool NTX = false>
 __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, typename std::conditional<ZV, double, const double>::type *v, double *x,
                                                        const double *diag, size_t n, const double *sc, const int *st)
 {
@@ -2994,8 +2996,14 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, ty
       if (i + 1 < n) {
         pv[u] = *reinterpret_cast<double2 *>(p + i);
         rv[u] = *reinterpret_cast<double2 *>(r + i);
-        if (MODE != 0 && !done) vv[u] = *reinterpret_cast<const double2 *>(v + i);
-        if (touch_x) xv[u] = *reinterpret_cast<double2 *>(x + i);
+        if (MODE != 0 && !done) {
+          if constexpr (NTX) { const bp5_d2u t = __builtin_nontemporal_load(reinterpret_cast<const bp5_d2u *>(v + i)); vv[u] = double2{t.x, t.y}; }
+          else vv[u] = *reinterpret_cast<const double2 *>(v + i);
+        }
+        if (touch_x) {
+          if constexpr (NTX) { const bp5_d2u t = __builtin_nontemporal_load(reinterpret_cast<const bp5_d2u *>(x + i)); xv[u] = double2{t.x, t.y}; }
+          else xv[u] = *reinterpret_cast<double2 *>(x + i);
+        }
       } else if (i < n) {
         pv[u].x = p[i]; rv[u].x = r[i];
         if (MODE != 0 && !done) vv[u].x = v[i];
@@ -3015,7 +3023,10 @@ __global__ void __launch_bounds__(VB) cgm_update_kernel(double *p, double *r, ty
           *reinterpret_cast<double2 *>(p + i) = pv[u];
           if (MODE != 0) *reinterpret_cast<double2 *>(r + i) = rv[u];
         }
-        if (touch_x) *reinterpret_cast<double2 *>(x + i) = xv[u];
+        if (touch_x) {
+          if constexpr (NTX) __builtin_nontemporal_store(bp5_d2u{xv[u].x, xv[u].y}, reinterpret_cast<bp5_d2u *>(x + i));
+          else *reinterpret_cast<double2 *>(x + i) = xv[u];
+        }
         if constexpr (ZV) { if (MODE != 0 && !done) *reinterpret_cast<double2 *>(v + i) = double2{0.0, 0.0}; }
       } else {
         if (touch_rp) { p[i] = pv[u].x; if (MODE != 0) r[i] = rv[u].x; }

@@ -155,6 +155,10 @@ class MatrixFree:
     def set_block_workgroups(self, n):
         _lib.check(_lib.lib().bp5_mf_set_block_workgroups(self.handle, int(n)))
 
+    def set_streaming(self, policy):
+        """1: non-temporal accesses to once-used data (metric planes; v, x in the update kernel), 0: ordinary, -1: by local size (default)."""
+        _lib.check(_lib.lib().bp5_mf_set_streaming(self.handle, int(policy)))
+
     def block_plan_info(self):
         """(n_blocks, max_runs, packed_indices) of the block kernel's plan."""
         nb, mr, pk = C.c_uint32(), C.c_uint32(), C.c_int()

@@ -250,6 +250,11 @@ int bp5_mf_set_apply_variant(bp5_mf *mf, int variant);
 /* cap on the persistent grid of the block-assembled kernel (0 = sized from the CU count; tuning / tests: a small cap
  * makes every workgroup walk several blocks even on a small mesh) */
 int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups);
+/* cache policy for the data a CG iteration touches ONCE (the metric planes in the p = 4 lattice block kernel; v and x in the merged solver's
+ * update kernel; results are the same bits either way): 1 = non-temporal accesses, so that this data does not evict the vectors that are
+ * reused (p, r) from the 256 MB memory-side cache (-6 % per CG iteration at 1e7 DoFs, +1 % at 1e8), 0 = ordinary accesses,
+ * -1 = chosen from the local size (default: non-temporal up to 2.4e7 local DoFs) */
+int bp5_mf_set_streaming(bp5_mf *mf, int policy);
 /* facts about the block kernel's plan for this handle (builds it): number of cell blocks, longest run-length list of a
  * block, and whether the packed one-u16-per-DoF index form is available (<= 128 runs per block; brick-major numbering
  * gives ~30, a slab's boundary bricks with their ghost rows ~70) -- every rank of a multi-GPU run should report 1 */

@@ -367,6 +367,38 @@ def test_deterministic_block_kernel_for_the_other_degrees(p, cells, block, quad)
     assert float((sols[0] - sols[1]).abs().max()) < 1e-11 * float(sols[1].abs().max())   # (only the summation order differs)
 
 
+def test_streaming_policy_changes_no_bit():
+    """bp5_mf_set_streaming: non-temporal accesses to once-used data (metric planes in the lattice block kernel, v and x in the update kernel: the
+    choice up to 2.4e7 local DoFs) and ordinary ones (beyond) are separate kernel builds -- same bits from the operator and from the merged CG
+    solve (an odd and an even iteration count: both update kernels and the epilogue), the kernel name tells which block kernel ran."""
+    torch = _t()
+    mesh = pkg.BrickMesh(4, (9, 8, 6), h=0.2, deform_amp=0.03, cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)
+    mf.set_block_workgroups(8)
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    src = torch.rand(mesh.n_owned, dtype=torch.float64, device="cuda:0", generator=g) - 0.5
+    b = op.assemble_rhs()
+    got = {}
+    for policy in (-1, 0, 1):
+        mf.set_streaming(policy)
+        d = op.initialize_dof_vector()
+        op.vmult(d, src)
+        xs = []
+        for its in (6, 7):
+            x = op.initialize_dof_vector()
+            ctl = pkg.IterationNumberControl(its, 0.0)
+            pkg.SolverCGFullMerge(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+            xs.append(x)
+        got[policy] = (d, xs[0], int(ctl.apply_kernel.split(",")[-1].rstrip(">")), xs[1])
+    assert got[1][2] & 32768 and got[-1][2] & 32768 and not got[0][2] & 32768 and got[0][2] & 16777216
+    for policy in (-1, 1):
+        assert all(torch.equal(got[policy][i], got[0][i]) for i in (0, 1, 3))
+    with pytest.raises(pkg.BP5Error):
+        mf.set_streaming(2)
+
+
 @pytest.mark.parametrize("p,cells,block,kw", [(4, (9, 8, 6), (4, 4, 4), {}), (4, (8, 8, 12), (4, 4, 2), dict(rank=1, n_ranks=2)), (4, (8, 8, 13), (4, 4, 4), dict(rank=1, n_ranks=3)),
                                             (1, (17, 9, 10), (8, 8, 8), {}), (2, (9, 8, 5), (8, 8, 4), {}), (3, (9, 5, 6), (8, 4, 4), dict(rank=1, n_ranks=2)),
                                             (5, (7, 5, 3), (6, 4, 2), {}), (6, (5, 4, 3), (4, 4, 2), {}), (7, (5, 3, 3), (4, 2, 2), {}), (8, (3, 3, 3), (2, 2, 2), {})])

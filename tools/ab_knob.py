@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""merged CG per-iteration time with a knob of the library at several values, interleaved in ONE process: an environment variable the library
+reads per solve (--knob BP5_EARLY_GATHER) or a setter of MatrixFree (--knob streaming -> mf.set_streaming(int(value)))
+usage: python tools/ab_knob.py --knob streaming --values 0 1 --cells 54 54 54 --cell-block 4 4 2"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bp5_pkg
+pkg = bp5_pkg.load()
+ap = argparse.ArgumentParser()
+ap.add_argument("--knob", default="streaming")
+ap.add_argument("--values", nargs="+", default=["0", "1"])
+ap.add_argument("--cells", type=int, nargs=3, default=[116, 116, 116])
+ap.add_argument("--cell-block", type=int, nargs=3, default=[4, 4, 4])
+ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--rounds", type=int, default=5)
+a = ap.parse_args()
+mesh = pkg.BrickMesh(4, a.cells, h=1.0 / a.cells[0], cell_block=a.cell_block, dof_numbering=1, cell_block_order=1)
+op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+b, x = op.assemble_rhs(), op.initialize_dof_vector()
+print("bricks", op.mf_data.block_plan_info()[0], "dofs", mesh.n_owned, flush=True)
+res = {}
+for rnd in range(a.rounds + 1):
+    for val in a.values:
+        if a.knob.startswith("BP5_"):
+            os.environ[a.knob] = val
+        else:
+            getattr(op.mf_data, "set_" + a.knob)(int(val))
+        ctl = pkg.IterationNumberControl(a.iters, 0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pkg.SolverCGFullMerge(ctl, profile=True).solve(op, x, b, pkg.DiagonalMatrix())
+        torch.cuda.synchronize()
+        if rnd:
+            res.setdefault(val, []).append(((time.perf_counter() - t0) / a.iters * 1e3, ctl.apply_ms_avg, ctl.apply_kernel))
+for val, r in res.items():
+    ms = sorted(x[0] for x in r)
+    print(f"{a.knob}={val}: median {ms[len(ms) // 2]:.4f} min {ms[0]:.4f} ms/iteration, cell kernel {min(x[1] for x in r):.4f} ms  {r[0][2]}")
