@@ -272,6 +272,31 @@ int build_team_plan(const uint32_t *l2g, uint32_t n_cells, int n3, size_t n_loca
               break;
             }
       }
+      // dissolve the emptiest pass into the free slots of the others as long as that saves a pass (e.g. p = 5, 6x4x2 bricks, 7 cells per pass:
+      // 8 parity classes of 6 cells -> 7 passes, the eighth class spread one cell per pass, in a second round)
+      for (;;) {
+        const int np = (int)fill.size();
+        int total = 0, qs = -1;
+        for (int q = 0; q < np; ++q) { total += fill[q]; if (fill[q] > 0 && (qs < 0 || fill[q] <= fill[qs])) qs = q; }
+        if (np < 2 || qs < 0 || total > (np - 1) * cells_per_pass) break;
+        std::vector<uint8_t> top(np, 0); // highest round of every pass BEFORE it absorbs anything: the absorbed cells keep their mutual order
+        for (int q = 0; q < np; ++q)
+          for (int k = 0; k < fill[q]; ++k) top[q] = std::max<uint8_t>(top[q], out.cell_round[passes[(size_t)q * cells_per_pass + k]]);
+        for (int k = 0; k < fill[qs]; ++k) {
+          const uint32_t cb = passes[(size_t)qs * cells_per_pass + k];
+          int qa = -1;
+          for (int q = 0; q < np; ++q) if (q != qs && fill[q] < cells_per_pass && (qa < 0 || fill[q] < fill[qa])) qa = q;
+          if ((int)out.cell_round[cb] + top[qa] + 1 > 254) {
+#pragma omp atomic write
+            too_many_rounds = 1;
+          }
+          out.cell_round[cb] = (uint8_t)std::min<int>(254, out.cell_round[cb] + top[qa] + 1);
+          nr = std::max<uint8_t>(nr, out.cell_round[cb] + 1);
+          passes[(size_t)qa * cells_per_pass + fill[qa]++] = cb;
+        }
+        passes.erase(passes.begin() + (size_t)qs * cells_per_pass, passes.begin() + (size_t)(qs + 1) * cells_per_pass);
+        fill.erase(fill.begin() + qs);
+      }
       out.team_rounds[t] = nr;
       // idle slots repeat the pass's first cell, flagged by bit 31
       for (size_t q = 0; q < fill.size(); ++q)
