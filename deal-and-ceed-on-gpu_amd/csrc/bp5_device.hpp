@@ -262,10 +262,9 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
 {
   constexpr int n = P + 1;
   constexpr int CPT = 256 / LPC;
-  using L = LdsLayout<n, LPC>;
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -CPT, &dp));
-  const size_t tile_cs = (ABL & 8192) ? (size_t)(n * L::PS + 3) : (size_t)L::CS;
+  const size_t tile_cs = (size_t)BlockPass<P, COLL, LPC, SC_OWNER_SET, ABL>::TILE_CS; // (two tiles per cell slot where the cells span waves: BlockPass::PP)
   const size_t lds = ((size_t)CPT * tile_cs + ((ABL & 524288) ? 2 : 1) * (size_t)dp->max_list) * sizeof(double) +
                      ((ABL & 16384) ? (4 * BLOCK_MAX_RUNS + 2 * BLOCK_LATTICE_WORDS) * sizeof(uint32_t) : 0); // run tables + lattice tables (two blocks each)
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");

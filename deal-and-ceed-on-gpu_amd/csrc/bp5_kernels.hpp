@@ -1154,6 +1154,32 @@ __device__ __forceinline__ void load_pencil_idx(const T *base, int ab, T (&v)[n]
 // rare wrong sums in multi-round passes at full size).  tools/check_lds_barrier.py checks the ISA for this pattern.
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// degrees whose block-kernel cells span waves (n^2 lanes per cell: p = 2, 5, 8) and exchange their tiles through the workgroup barrier: two
+// tiles used alternately halve the barriers of a pass (BlockPass::PP) where the second tile still fits the LDS share of the workgroup
+#ifndef BP5_PINGPONG_P2
+#define BP5_PINGPONG_P2 1
+#endif
+#ifndef BP5_PINGPONG_P5
+#define BP5_PINGPONG_P5 0
+#endif
+#ifndef BP5_PINGPONG_P8
+#define BP5_PINGPONG_P8 1
+#endif
+constexpr bool block_pingpong(int degree) { return degree == 2 ? BP5_PINGPONG_P2 != 0 : degree == 5 ? BP5_PINGPONG_P5 != 0 : degree == 8 ? BP5_PINGPONG_P8 != 0 : false; }
+
+// tile strides of the block kernel (doubles): LdsLayout's, except for the cell shapes that span waves (p = 2, 5, 8), where the bank conflicts of
+// all four waves of the workgroup count (tools/lds_stride_search.py --block; weighted LDS cycles per pass against LdsLayout's strides:
+// n = 9: 363 / 551, n = 3: 397 / 805 with two tiles, n = 6: 399 / 445).  ONE: one tile, SLOT: cell slot stride of the sequential-tile
+// builds (PP: two tiles)
+template <int n, int LPC, bool PP>
+struct BlockLayout {
+  using B = LdsLayout<n, LPC>;
+  static constexpr int RS = B::RS, PS = B::PS, CS = B::CS, ONE = n * PS + 3, SLOT = (PP ? 2 : 1) * ONE;
+};
+template <> struct BlockLayout<9, 81, true> { static constexpr int RS = 9, PS = 81, CS = 3 * 9 * 81 + 1, ONE = 732, SLOT = 1465; };
+template <> struct BlockLayout<3, 9, true> { static constexpr int RS = 4, PS = 19, CS = 3 * 3 * 19 + 1, ONE = 60, SLOT = 121; };
+template <> struct BlockLayout<6, 36, false> { static constexpr int RS = 7, PS = 42, CS = 3 * 6 * 42 + 1, ONE = 252, SLOT = 252; };
+
 constexpr int BLOCK_MAX_RUNS = 128;
 // run table entry "first DoF": bit 31 = the run's DoFs are touched by this block only (owner stores), bit 30 = Dirichlet DoFs
 // (builds with fused dot products write src there: copy_constrained_values folded into the write-out); DoF indices < 2^30
@@ -1240,7 +1266,6 @@ struct BlockPass {
   static constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
   static constexpr int TEAM = 256;
   static constexpr int CPT = TEAM / LPC;
-  using L = LdsLayout<n, LPC>;
   static constexpr bool AFFINE = (ABL & 1024) != 0;
   // SINGLE: the metric of a pass is loaded at the top of that pass (as in apply_pencil_kernel) and only the
   // indices / gathered values are prefetched one pass ahead: ~60 fewer VGPRs -> three workgroups per CU
@@ -1272,11 +1297,22 @@ struct BlockPass {
   static_assert(!STAGE || (PACK && (ABL & 16384)), "LDS-staged src needs packed indices and the run table");
   static constexpr bool SEQ = (ABL & 8192) != 0;
   // (p = 8: 81 lanes per cell span two waves; the tile exchanges then use the workgroup barrier -- correct, every lane reaches every sync)
-  static constexpr int TILE_CS = SEQ ? (n * L::PS + 3) : L::CS; // doubles per cell slot
+  // PP: cells that span waves exchange their tiles through the WORKGROUP barrier (20 barriers per pass with one tile: write, barrier, read,
+  // barrier, field after field).  Two tiles used alternately need no barrier behind the reads -- the next field goes to the OTHER tile, and
+  // by the time a tile is written again every lane has passed the barrier of the field in between: half the barriers per pass
+  static constexpr bool PP = SEQ && !WAVE_LOCAL && block_pingpong(P);
+  using L = BlockLayout<n, LPC, PP>;
+  static constexpr int TILE_ONE = L::ONE;
+  static constexpr int TILE_CS = SEQ ? L::SLOT : L::CS; // doubles per cell slot
   static __device__ __forceinline__ void tile_sync()
   {
     if constexpr (WAVE_LOCAL) team_sync<1>();
     else __syncthreads();
+  }
+  // the barrier behind the READS of a tile (write-after-read): not needed between alternating tiles
+  static __device__ __forceinline__ void tile_sync_r()
+  {
+    if constexpr (!PP) tile_sync();
   }
 
   // issue index / position / metric loads of the cell named by r.ent
@@ -1367,6 +1403,7 @@ struct BlockPass {
     BP5_STAMP(0) // issue of this pass's loads
     if constexpr (SEQ) {
 #define T1(k, j, i) T[(k) * L::PS + (j) * L::RS + (i)]
+#define T2(k, j, i) T[(PP ? TILE_ONE : 0) + (k) * L::PS + (j) * L::RS + (i)]
       const bool act = cur.active;
       double(&uu)[n] = cur.u;
       bool hang_any = false;
@@ -1389,15 +1426,15 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int j = 0; j < n; ++j) vN[j] = T1(b_, j, a_);
-        tile_sync();
+        tile_sync_r();
         if (act) {
 #pragma unroll
-          for (int k = 0; k < n; ++k) T1(k, b_, a_) = aD[k];
+          for (int k = 0; k < n; ++k) T2(k, b_, a_) = aD[k];
         }
         tile_sync();
 #pragma unroll
-        for (int j = 0; j < n; ++j) vD[j] = T1(b_, j, a_);
-        tile_sync();
+        for (int j = 0; j < n; ++j) vD[j] = T2(b_, j, a_);
+        tile_sync_r();
         double c1[n], c2[n], c3[n], r1[n], r2[n], r3[n];
         MV_N(sh.N, vN, c1);
         MV_D(sh.D, vN, c2);
@@ -1409,15 +1446,15 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int i = 0; i < n; ++i) r1[i] = T1(b_, a_, i);
-        tile_sync();
+        tile_sync_r();
         if (act) {
 #pragma unroll
-          for (int j = 0; j < n; ++j) T1(b_, j, a_) = c2[j];
+          for (int j = 0; j < n; ++j) T2(b_, j, a_) = c2[j];
         }
         tile_sync();
 #pragma unroll
-        for (int i = 0; i < n; ++i) r2[i] = T1(b_, a_, i);
-        tile_sync();
+        for (int i = 0; i < n; ++i) r2[i] = T2(b_, a_, i);
+        tile_sync_r();
         if (act) {
 #pragma unroll
           for (int j = 0; j < n; ++j) T1(b_, j, a_) = c3[j];
@@ -1425,7 +1462,7 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int i = 0; i < n; ++i) r3[i] = T1(b_, a_, i);
-        tile_sync();
+        tile_sync_r();
         MV_D(sh.D, r1, q0);
         MV_N(sh.N, r2, q1);
         MV_N(sh.N, r3, q2);
@@ -1442,16 +1479,16 @@ struct BlockPass {
         for (int j = 0; j < n; ++j) vN[j] = T1(b_, j, a_);
 #pragma unroll
         for (int i = 0; i < n; ++i) r1[i] = T1(b_, a_, i);
-        tile_sync();
+        tile_sync_r();
         MV_D(sh.D, vN, c2);
         if (act) {
 #pragma unroll
-          for (int j = 0; j < n; ++j) T1(b_, j, a_) = c2[j];
+          for (int j = 0; j < n; ++j) T2(b_, j, a_) = c2[j];
         }
         tile_sync();
 #pragma unroll
-        for (int i = 0; i < n; ++i) q1[i] = T1(b_, a_, i);
-        tile_sync();
+        for (int i = 0; i < n; ++i) q1[i] = T2(b_, a_, i);
+        tile_sync_r();
         if (act) {
 #pragma unroll
           for (int k = 0; k < n; ++k) T1(k, b_, a_) = gz[k];
@@ -1459,7 +1496,7 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int i = 0; i < n; ++i) q2[i] = T1(b_, a_, i);
-        tile_sync();
+        tile_sync_r();
         MV_D(sh.D, r1, q0);
         if constexpr (HELM) {
 #pragma unroll
@@ -1501,12 +1538,12 @@ struct BlockPass {
         MV_NT(sh.N, q2, e3);
         if (act) {
 #pragma unroll
-          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e1[i];
+          for (int i = 0; i < n; ++i) T2(b_, a_, i) = e1[i];
         }
         tile_sync();
 #pragma unroll
-        for (int j = 0; j < n; ++j) w1[j] = T1(b_, j, a_);
-        tile_sync();
+        for (int j = 0; j < n; ++j) w1[j] = T2(b_, j, a_);
+        tile_sync_r();
         if (act) {
 #pragma unroll
           for (int i = 0; i < n; ++i) T1(b_, a_, i) = e2[i];
@@ -1514,15 +1551,15 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int j = 0; j < n; ++j) w2[j] = T1(b_, j, a_);
-        tile_sync();
+        tile_sync_r();
         if (act) {
 #pragma unroll
-          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e3[i];
+          for (int i = 0; i < n; ++i) T2(b_, a_, i) = e3[i];
         }
         tile_sync();
 #pragma unroll
-        for (int j = 0; j < n; ++j) w3[j] = T1(b_, j, a_);
-        tile_sync();
+        for (int j = 0; j < n; ++j) w3[j] = T2(b_, j, a_);
+        tile_sync_r();
         double f1[n], f2[n], z1[n], z2[n];
         MV_NT(sh.N, w1, f1);
         MV_DT_ADD(sh.D, w2, f1);
@@ -1534,15 +1571,15 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int k = 0; k < n; ++k) z1[k] = T1(k, b_, a_);
-        tile_sync();
+        tile_sync_r();
         if (act) {
 #pragma unroll
-          for (int j = 0; j < n; ++j) T1(b_, j, a_) = f2[j];
+          for (int j = 0; j < n; ++j) T2(b_, j, a_) = f2[j];
         }
         tile_sync();
 #pragma unroll
-        for (int k = 0; k < n; ++k) z2[k] = T1(k, b_, a_);
-        tile_sync();
+        for (int k = 0; k < n; ++k) z2[k] = T2(k, b_, a_);
+        tile_sync_r();
         MV_NT(sh.N, z1, yy);
         MV_DT_ADD(sh.D, z2, yy);
       } else {
@@ -1555,12 +1592,12 @@ struct BlockPass {
         // y-direction: w1 = e1 + D^T q1 (both re-oriented x-owner -> y-owner)
         if (act) {
 #pragma unroll
-          for (int i = 0; i < n; ++i) T1(b_, a_, i) = e1[i];
+          for (int i = 0; i < n; ++i) T2(b_, a_, i) = e1[i];
         }
         tile_sync();
 #pragma unroll
-        for (int j = 0; j < n; ++j) w1[j] = T1(b_, j, a_);
-        tile_sync();
+        for (int j = 0; j < n; ++j) w1[j] = T2(b_, j, a_);
+        tile_sync_r();
         if (act) {
 #pragma unroll
           for (int i = 0; i < n; ++i) T1(b_, a_, i) = q1[i];
@@ -1568,16 +1605,16 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int j = 0; j < n; ++j) w2[j] = T1(b_, j, a_);
-        tile_sync();
+        tile_sync_r();
         MV_DT_ADD(sh.D, w2, w1);
         if (act) {
 #pragma unroll
-          for (int j = 0; j < n; ++j) T1(b_, j, a_) = w1[j];
+          for (int j = 0; j < n; ++j) T2(b_, j, a_) = w1[j];
         }
         tile_sync();
 #pragma unroll
-        for (int k = 0; k < n; ++k) yy[k] = T1(k, b_, a_);
-        tile_sync();
+        for (int k = 0; k < n; ++k) yy[k] = T2(k, b_, a_);
+        tile_sync_r();
         if (act) {
 #pragma unroll
           for (int i = 0; i < n; ++i) T1(b_, a_, i) = q2[i];
@@ -1585,7 +1622,7 @@ struct BlockPass {
         tile_sync();
 #pragma unroll
         for (int k = 0; k < n; ++k) z2[k] = T1(k, b_, a_);
-        tile_sync();
+        tile_sync_r();
         MV_DT_ADD(sh.D, z2, yy);
       }
       if constexpr (HANG) { if (hang_any) pencil_hang_resolve<n, WAVE_LOCAL ? 1 : 4, true, L>(cur.mask, a.hang_I, yy, T, a_, b_, act); } // adjoint
@@ -1603,6 +1640,7 @@ struct BlockPass {
       }
       BP5_STAMP(5)
 #undef T1
+#undef T2
       return;
     }
 #define TL(f, k, j, i) T[(f) * (n * L::PS) + (k) * L::PS + (j) * L::RS + (i)]

@@ -46,7 +46,43 @@ def search(n, LPC):
                     best = (score, RS, PS, CS, rd, wr)
     return best
 
+def evaluate_block(n, LPC, RS, PS, SLOT):
+    """block kernel, cells that span waves (n^2 lanes per cell, 256 // LPC cells per 256-thread workgroup): all four waves count"""
+    n2, CPT = n * n, 256 // LPC
+    rd, wr = [0, 0, 0], [0, 0, 0]
+    for w in range(4):
+        for ki, kind in enumerate("zyx"):
+            addrs = []
+            for t in range(64 * w, 64 * w + 64):
+                c, ab = divmod(t, LPC)
+                if ab >= n2 or c >= CPT: addrs.append(None); continue
+                a, b = ab % n, ab // n
+                addrs.append(c * SLOT + (b * RS + a if kind == "z" else b * PS + a if kind == "y" else b * PS + a * RS))
+            rd[ki] += cost(addrs, 32, 32)
+            wr[ki] += cost(addrs, 16, 16)
+    return rd, wr
+
+def block_score(rd, wr):
+    # sequential-tile pass (BlockPass::run): writes z x2, y x5, x x3; reads z x2, y x5, x x3
+    return 2 * rd[0] + 5 * rd[1] + 3 * rd[2] + 2 * wr[0] + 5 * wr[1] + 3 * wr[2]
+
+def search_block(n, LPC, tiles):
+    """tiles = 2: two tiles per cell slot (BlockPass::PP); SLOT >= tiles * n * PS"""
+    res = []
+    for RS in (n, n + 1, n + 2):
+        for PS in range(n * RS, n * RS + 20):
+            for SLOT in range(tiles * n * PS, tiles * n * PS + 49):
+                rd, wr = evaluate_block(n, LPC, RS, PS, SLOT)
+                res.append((block_score(rd, wr), SLOT, RS, PS, rd, wr))
+    res.sort(key=lambda x: (x[0], x[1]))
+    return res[:3]
+
 if __name__ == "__main__":
+    if "--block" in sys.argv:   # BlockLayout specialisations of csrc/bp5_kernels.hpp
+        for n, LPC, tiles in ((9, 81, 2), (3, 9, 2), (6, 36, 1)):
+            for r in search_block(n, LPC, tiles):
+                print(f"n={n} LPC={LPC} tiles={tiles}: weighted cycles {r[0]} SLOT={r[1]} RS={r[2]} PS={r[3]} read(z,y,x)={r[4]} write={r[5]}")
+        sys.exit(0)
     for n in range(2, 10):
         n2 = n * n
         opts = sorted({min(64, n2), *( [32] if n2 <= 32 else []), *([16] if n2 <= 16 else [])})
