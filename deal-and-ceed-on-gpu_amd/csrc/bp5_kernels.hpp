@@ -1304,6 +1304,8 @@ struct BlockPass {
   using L = BlockLayout<n, LPC, PP>;
   static constexpr int TILE_ONE = L::ONE;
   static constexpr int TILE_CS = SEQ ? L::SLOT : L::CS; // doubles per cell slot
+  static_assert((n - 1) * (L::PS + L::RS + 1) < L::ONE, "a tile holds every (k, j, i) entry");
+  static_assert(L::SLOT >= (PP ? 2 : 1) * L::ONE && L::CS >= 3 * n * L::PS, "cell slot holds its tiles");
   static __device__ __forceinline__ void tile_sync()
   {
     if constexpr (WAVE_LOCAL) team_sync<1>();
