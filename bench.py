@@ -182,6 +182,10 @@ def main():
     ap.add_argument("--no-traffic-pass", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only); the committed passes of "
                          "profiles/*/traffic.json are quoted instead.  Needed under an outer profiler.")
+    ap.add_argument("--post-budget", type=float, default=None,
+                    help="seconds the legs AFTER the timed region may take (sustained solves, unfused solve, exchange A/B, copy stream, traffic passes, CPU "
+                         "baseline); then the line is printed with what is there and the process exits 0 (default: 600 at N = 1, 240 at N > 1) -- a hang in a "
+                         "diagnostic leg of the first real multi-GPU run must not cost the measurement")
     ap.add_argument("--no-exchange-ab", action="store_true",
                     help="N > 1: skip the diagnostic solves after the timed region (unsplit vs boundary-first exchange, phase stamps)")
     ap.add_argument("--rehearsal", action="store_true",
@@ -323,103 +327,27 @@ def main():
     n_global = int(mesh.n_global_dofs)
     value = n_global * iters / dt
 
-    # the reference's own protocol (bp5/step-64.cu:443-463,724-730): solves of 200 iterations, wall clock + device sync
-    # around each, the BEST repetition is reported.  Minutes-long runs clock ~5 % below short bursts (profiles/r1 j_*).
-    sustained = None
-    if args.sustained_iters > 0 and args.sustained_reps > 0:
-        best = 0.0
-        for _ in range(args.sustained_reps):
-            sctl, sdt = timed_solve(args.sustained_iters, profile=False)
-            best = max(best, n_global * sctl.last_step() / sdt)
-        sustained = {"value": best, "unit": "DoF/s", "iterations": args.sustained_iters, "repetitions": args.sustained_reps,
-                     "protocol": "reference: best of n repetitions of one solve, wall clock incl. device sync (bp5/step-64.cu:457-463,724-730)"}
+    # Everything below is reporting around the measurement above.  The legs fill `extras`; compose() (defined further down) builds the line
+    # from whatever is there.  A watchdog prints the line and ends the process (exit code 0, every rank) if the legs take longer than
+    # --post-budget: a diagnostic leg that hangs (a collective only some ranks entered, a schedule the node does not support) must not
+    # cost the run its measurement.
+    import threading
+    extras = {"stage": "sustained solves", "fused_all": bool(ctl.dot_products_fused), "fused_any": bool(ctl.dot_products_fused)}
+    post_budget = args.post_budget if args.post_budget is not None else (600.0 if world == 1 else 240.0)
+    compose_ref, printed = [], threading.Lock()
 
-    # every rank decides fused / unfused from its own brick plan: agree before anything collective branches on it
-    fused_all = bool(reduce_ranks(1.0 if ctl.dot_products_fused else 0.0, "min"))
-    fused_any = bool(reduce_ranks(1.0 if ctl.dot_products_fused else 0.0, "max"))
-
-    # the bare operator kernel in the same run (when the timed solve fused the dot products into it): a short solve with the
-    # separate dot-product kernel, so that the operator-only roofline figure of SURVEY 8(d) can be read off the same box
-    unfused_ms = None
-    if fused_all:
-        op.mf_data.set_cg_fusion(False)
-        uctl, _ = timed_solve(10)
-        unfused_ms = uctl.apply_ms_avg
-        op.mf_data.set_cg_fusion(True)
-
-    # N > 1 diagnostics: the same solve in both exchange schedules, each once plainly timed and once with phase stamps (HIP events at
-    # the phase boundaries of every iteration on the solver's stream; the stamps cost a few us each, so the stamped run is not the timed
-    # one).  One driver run then tells how much of an iteration is kernels, exposed exchange, and all-reduce -- per rank extremes.
-    exchange_ab = None
-    if world > 1 and not args.no_exchange_ab and args.variant == "merged":
-        exchange_ab = {}
-        k_ab = max(10, min(args.steps, 40))
-        for mode, name in ((0, "unsplit"), (1, "boundary_first"), (2, "automatic")):
+    def watchdog_fire():
+        if rank == 0 and compose_ref and printed.acquire(blocking=False):
             try:
-                op.mf_data.set_overlap(mode)
-                timed_solve(3)
-                actl, adt = timed_solve(k_ab, profile=False)
-                pctl, _ = timed_solve(min(k_ab, 32), profile=2)
-                entry = {"ms_per_iteration": adt / max(actl.last_step(), 1) * 1e3, "iterations": actl.last_step(),
-                         "schedule_rank0": SCHEDULES.get(actl.exchange_schedule, "?"), "dot_products_fused_rank0": bool(actl.dot_products_fused),
-                         "phases_ms_max_over_ranks": {}, "phases_ms_min_over_ranks": {}}
-                for i, ph in enumerate(PHASES):
-                    entry["phases_ms_max_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "max")
-                    entry["phases_ms_min_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "min")
-                exchange_ab[name] = entry
+                print(json.dumps(compose_ref[0](False)), flush=True)
             except Exception as e:   # noqa: BLE001
-                die(f"exchange A/B leg '{name}' (bp5_mf_set_overlap({mode}))", e)
-        op.mf_data.set_overlap(args.overlap)
-        exchange_ab["note"] = ("same problem, same kernels, same bits; unsplit = gather, one launch, combine, scatter-add on the compute stream; "
-                               "boundary_first = ghost-touching bricks first inside the launch, ghost rows + scatter-add on the communication stream "
-                               "under the interior bricks; automatic = the library's default: one launch, ghost rows combined first, scatter-add on "
-                               "the communication stream under the owned-row combine.  phases: HIP "
-                               "events on the solver's stream (exchange = exposed part incl. unpack; gather_wait = exposed part of the ghost "
-                               "gather that travels under the vector update)")
-
-    # achievable-stream figure (SURVEY 8d): device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
-    import ctypes as C
-    ya, xa = op.initialize_dof_vector(), op.initialize_dof_vector()
-    L, hnd = pkg.lib(), op.mf_data.handle
-    pv = lambda t: C.c_void_p(t.data_ptr())
-    for _ in range(3):
-        L.bp5_vec_equ(hnd, pv(ya), 1.0, pv(xa), mesh.n_owned)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        L.bp5_vec_equ(hnd, pv(ya), 1.0, pv(xa), mesh.n_owned)
-    e1.record()
-    torch.cuda.synchronize()
-    stream_copy_gbs = 16.0 * mesh.n_owned * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del ya, xa
-
-    # BASELINE config 4 as one line: the other degrees at their ~5e7-DoF sizes, one short solve each (N = 1)
-    sweep = None
-    if args.config == 4 and world == 1:
-        sweep = []
-        for q in range(1, 9):
-            if q == p and not args.cells:
-                r_q = mesh.n_cells * (q + 1) ** 3 / mesh.n_owned
-                sweep.append({"degree": q, "cells": list(cells), "dofs": n_global, "value": value, "ms_per_step": dt / max(iters, 1) * 1e3,
-                              "kernel": ctl.apply_kernel, "frac_of_hbm_peak": value * algorithmic_bytes_per_dof(q, mesh.n_cells, mesh.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
-                continue
-            nq = CONFIG_SIZES[q]
-            mq, _, _ = build(q, (nq, nq, nq))
-            oq = pkg.HelmholtzOperator(mq, quad, km, device=local_rank) if args.operator == "helmholtz" else \
-                pkg.PoissonOperator(mq, quad, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
-            bq, xq = oq.assemble_rhs(), oq.initialize_dof_vector()
-            timed_solve(3, oq, xq, bq)
-            cq, dq = timed_solve(max(10, min(args.steps, 30)), oq, xq, bq)
-            vq = int(mq.n_global_dofs) * cq.last_step() / dq
-            sweep.append({"degree": q, "cells": [nq, nq, nq], "dofs": int(mq.n_global_dofs), "value": vq, "ms_per_step": dq / max(cq.last_step(), 1) * 1e3,
-                          "kernel": cq.apply_kernel, "dot_products_fused": bool(cq.dot_products_fused),
-                          "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
-            oq.mf_data.close()
-            del oq, bq, xq, mq
-            torch.cuda.empty_cache()
-
-    if rank == 0:
+                sys.stderr.write(f"[bench rank 0] watchdog could not compose the line: {type(e).__name__}: {e}\n")
+        sys.stderr.write(f"[bench rank {rank}/{world}] post-processing exceeded {post_budget:.0f} s in stage '{extras['stage']}': line printed without it, exiting\n")
+        sys.stderr.flush()
+        os._exit(0)
+    watchdog = threading.Timer(post_budget, watchdog_fire)
+    def compose(final):
+        """the JSON line from the timed solve and whatever the later legs have put into `extras` (watchdog: final = False)"""
         n_cells_local, n_dofs_local = mesh.n_cells, mesh.n_owned
         r = n_cells_local * (p + 1) ** 3 / n_dofs_local
         B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
@@ -444,16 +372,8 @@ def main():
             lattice_kernel = False
         idx_moved = 4.0 * r / (p + 1) ** 3 if lattice_kernel else 2.0 * r
         B_moved = (16.0 + idx_moved + G * 8.0 * r + (8.0 if fused else 0.0)) if block_kernel else B_kernel
-        tr = None
-        if world == 1 and not args.no_traffic_pass and not args.rehearsal:
-            wl = ["--operator", args.operator, "--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
-                  "--variant", args.variant, "--geometry", args.geometry, "--apply-variant", str(args.apply_variant),
-                  "--cells", str(cells[0]), str(cells[1]), str(cells[2]), "--cell-block", str(block[0]), str(block[1]), str(block[2])]
-            tr = live_traffic(kname, wl)
-        if tr is None and args.deform == 0.0 and world == 1:
-            tr = measured_traffic(key, kname)
-            if tr:
-                tr["source"] += ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (not measured in this run)"
+        sustained, unfused_ms, exchange_ab, sweep = extras.get("sustained"), extras.get("unfused_ms"), extras.get("exchange_ab"), extras.get("sweep")
+        fused_all, fused_any, stream_copy_gbs, tr = extras["fused_all"], extras["fused_any"], extras.get("stream_copy_gbs"), extras.get("traffic")
         out = {
             "metric": "BP5 DoFs/sec per CG iter (p=4, ~1e8 DoFs) + % HBM roofline at 1/2/4/8 GPUs",
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": iters, "warmup": args.warmup,
@@ -475,7 +395,7 @@ def main():
             # of 24 B for the dot products), which is why frac_of_stream_copy can exceed 1; bytes_moved_per_dof prices what is really moved
             "roofline_cg": {"basis": "contract formula (SURVEY 8d), not measured bytes", "bytes_per_dof": B,
                             "achieved_GBs_per_gpu": value / world * B / 1e9, "frac_of_hbm_peak": value / world * B / 1e9 / HBM_PEAK_GBS,
-                            "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": value / world * B / 1e9 / stream_copy_gbs,
+                            "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": (value / world * B / 1e9 / stream_copy_gbs) if stream_copy_gbs else None,
                             # merged CG as implemented: update kernels 40 / 56 B/DoF alternating (the operator overwrites v: no v write, x every
                             # second iteration) = 48 on average instead of the formula's 64; separate dot-product pass 24 when not fused
                             "bytes_moved_per_dof": (B_moved + 48.0 + (0.0 if fused else 24.0)) if args.variant == "merged" else None,
@@ -519,9 +439,146 @@ def main():
             out["exchange_ab"] = exchange_ab
         if sweep:
             out["sweep"] = sweep
+        if extras.get("cpu_baseline"):
+            out["cpu_baseline"] = extras["cpu_baseline"]
+        out["post_processing"] = {"completed": bool(final), "stage_reached": None if final else extras["stage"], "budget_s": post_budget}
+        return out
+    compose_ref.append(compose)
+    watchdog.daemon = True
+    watchdog.start()
+
+    # the reference's own protocol (bp5/step-64.cu:443-463,724-730): solves of 200 iterations, wall clock + device sync
+    # around each, the BEST repetition is reported.  Minutes-long runs clock ~5 % below short bursts (profiles/r1 j_*).
+    sustained = None
+    if args.sustained_iters > 0 and args.sustained_reps > 0:
+        best = 0.0
+        for _ in range(args.sustained_reps):
+            sctl, sdt = timed_solve(args.sustained_iters, profile=False)
+            best = max(best, n_global * sctl.last_step() / sdt)
+        sustained = {"value": best, "unit": "DoF/s", "iterations": args.sustained_iters, "repetitions": args.sustained_reps,
+                     "protocol": "reference: best of n repetitions of one solve, wall clock incl. device sync (bp5/step-64.cu:457-463,724-730)"}
+    extras["sustained"] = sustained
+    extras["stage"] = "fused / unfused agreement across ranks"
+
+    # every rank decides fused / unfused from its own brick plan: agree before anything collective branches on it
+    fused_all = bool(reduce_ranks(1.0 if ctl.dot_products_fused else 0.0, "min"))
+    fused_any = bool(reduce_ranks(1.0 if ctl.dot_products_fused else 0.0, "max"))
+    extras["fused_all"], extras["fused_any"] = fused_all, fused_any
+    extras["stage"] = "short solve with the separate dot-product kernel"
+
+    # the bare operator kernel in the same run (when the timed solve fused the dot products into it): a short solve with the
+    # separate dot-product kernel, so that the operator-only roofline figure of SURVEY 8(d) can be read off the same box
+    unfused_ms = None
+    if fused_all:
+        op.mf_data.set_cg_fusion(False)
+        uctl, _ = timed_solve(10)
+        unfused_ms = uctl.apply_ms_avg
+        op.mf_data.set_cg_fusion(True)
+    extras["unfused_ms"] = unfused_ms
+
+    # N > 1 diagnostics: the same solve in both exchange schedules, each once plainly timed and once with phase stamps (HIP events at
+    # the phase boundaries of every iteration on the solver's stream; the stamps cost a few us each, so the stamped run is not the timed
+    # one).  One driver run then tells how much of an iteration is kernels, exposed exchange, and all-reduce -- per rank extremes.
+    exchange_ab = None
+    if world > 1 and not args.no_exchange_ab and args.variant == "merged":
+        exchange_ab = {}
+        k_ab = max(10, min(args.steps, 40))
+        extras["exchange_ab"] = exchange_ab   # (filled leg by leg: the watchdog reports the legs that finished)
+        for mode, name in ((0, "unsplit"), (2, "automatic"), (1, "boundary_first")):   # (the default's legs first; boundary_first needs stream wait-value)
+            extras["stage"] = f"exchange A/B leg '{name}'"
+            try:
+                op.mf_data.set_overlap(mode)
+                timed_solve(3)
+                actl, adt = timed_solve(k_ab, profile=False)
+                pctl, _ = timed_solve(min(k_ab, 32), profile=2)
+                entry = {"ms_per_iteration": adt / max(actl.last_step(), 1) * 1e3, "iterations": actl.last_step(),
+                         "schedule_rank0": SCHEDULES.get(actl.exchange_schedule, "?"), "dot_products_fused_rank0": bool(actl.dot_products_fused),
+                         "phases_ms_max_over_ranks": {}, "phases_ms_min_over_ranks": {}}
+                for i, ph in enumerate(PHASES):
+                    entry["phases_ms_max_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "max")
+                    entry["phases_ms_min_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "min")
+                exchange_ab[name] = entry
+            except Exception as e:   # noqa: BLE001
+                # a diagnostic leg: report, skip the remaining legs (the other ranks may be inside a collective of this one: the watchdog ends that)
+                sys.stderr.write(f"[bench rank {rank}/{world}] exchange A/B leg '{name}' (bp5_mf_set_overlap({mode})) failed: {type(e).__name__}: {e}\n")
+                exchange_ab[name] = {"error": f"{type(e).__name__}: {e}"}
+                break
+        op.mf_data.set_overlap(args.overlap)
+        exchange_ab["note"] = ("same problem, same kernels, same bits; unsplit = gather, one launch, combine, scatter-add on the compute stream; "
+                               "boundary_first = ghost-touching bricks first inside the launch, ghost rows + scatter-add on the communication stream "
+                               "under the interior bricks; automatic = the library's default: one launch, ghost rows combined first, scatter-add on "
+                               "the communication stream under the owned-row combine.  phases: HIP "
+                               "events on the solver's stream (exchange = exposed part incl. unpack; gather_wait = exposed part of the ghost "
+                               "gather that travels under the vector update)")
+
+    # achievable-stream figure (SURVEY 8d): device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
+    extras["stage"] = "copy-stream measurement"
+    import ctypes as C
+    ya, xa = op.initialize_dof_vector(), op.initialize_dof_vector()
+    L, hnd = pkg.lib(), op.mf_data.handle
+    pv = lambda t: C.c_void_p(t.data_ptr())
+    for _ in range(3):
+        L.bp5_vec_equ(hnd, pv(ya), 1.0, pv(xa), mesh.n_owned)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        L.bp5_vec_equ(hnd, pv(ya), 1.0, pv(xa), mesh.n_owned)
+    e1.record()
+    torch.cuda.synchronize()
+    stream_copy_gbs = 16.0 * mesh.n_owned * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del ya, xa
+    extras["stream_copy_gbs"] = stream_copy_gbs
+
+    # BASELINE config 4 as one line: the other degrees at their ~5e7-DoF sizes, one short solve each (N = 1)
+    sweep = None
+    if args.config == 4 and world == 1:
+        sweep = []
+        extras["sweep"] = sweep
+        extras["stage"] = "config-4 degree sweep"
+        for q in range(1, 9):
+            if q == p and not args.cells:
+                r_q = mesh.n_cells * (q + 1) ** 3 / mesh.n_owned
+                sweep.append({"degree": q, "cells": list(cells), "dofs": n_global, "value": value, "ms_per_step": dt / max(iters, 1) * 1e3,
+                              "kernel": ctl.apply_kernel, "frac_of_hbm_peak": value * algorithmic_bytes_per_dof(q, mesh.n_cells, mesh.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
+                continue
+            nq = CONFIG_SIZES[q]
+            mq, _, _ = build(q, (nq, nq, nq))
+            oq = pkg.HelmholtzOperator(mq, quad, km, device=local_rank) if args.operator == "helmholtz" else \
+                pkg.PoissonOperator(mq, quad, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
+            bq, xq = oq.assemble_rhs(), oq.initialize_dof_vector()
+            timed_solve(3, oq, xq, bq)
+            cq, dq = timed_solve(max(10, min(args.steps, 30)), oq, xq, bq)
+            vq = int(mq.n_global_dofs) * cq.last_step() / dq
+            sweep.append({"degree": q, "cells": [nq, nq, nq], "dofs": int(mq.n_global_dofs), "value": vq, "ms_per_step": dq / max(cq.last_step(), 1) * 1e3,
+                          "kernel": cq.apply_kernel, "dot_products_fused": bool(cq.dot_products_fused),
+                          "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
+            oq.mf_data.close()
+            del oq, bq, xq, mq
+            torch.cuda.empty_cache()
+
+    if rank == 0:
+        extras["stage"] = "HBM traffic passes (rocprofv3 --pmc children)"
+        ev = op.mf_data.get_apply_variant()
+        key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}" + ("_helmholtz" if args.operator == "helmholtz" else "")
+        kname = ctl.apply_kernel or f"apply variant {ev}"
+        tr = None
+        if world == 1 and not args.no_traffic_pass and not args.rehearsal:
+            wl = ["--operator", args.operator, "--degree", str(p), "--quadrature", args.quadrature, "--coefficient", args.coefficient, "--deform", str(args.deform),
+                  "--variant", args.variant, "--geometry", args.geometry, "--apply-variant", str(args.apply_variant),
+                  "--cells", str(cells[0]), str(cells[1]), str(cells[2]), "--cell-block", str(block[0]), str(block[1]), str(block[2])]
+            tr = live_traffic(kname, wl)
+        if tr is None and args.deform == 0.0 and world == 1:
+            tr = measured_traffic(key, kname)
+            if tr:
+                tr["source"] += ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed (not measured in this run)"
+        extras["traffic"] = tr
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(mesh, p, quad, km, args.cpu_budget, max(args.steps, 2))
-        print(json.dumps(out), flush=True)
+            extras["stage"] = "CPU baseline"
+            extras["cpu_baseline"] = cpu_baseline(mesh, p, quad, km, args.cpu_budget, max(args.steps, 2))
+    watchdog.cancel()
+    if rank == 0 and printed.acquire(blocking=False):
+        print(json.dumps(compose(True)), flush=True)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.synchronize()

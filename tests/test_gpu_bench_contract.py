@@ -36,6 +36,7 @@ def _check(line, steps, warmup):
     assert r["kernel"].startswith("apply_") and 0 < r["frac_moved"] <= r["frac"] + 1e-12 and r["bytes_moved_per_dof"] <= r["bytes_per_dof"]
     assert "contract formula" in d["roofline_cg"]["basis"] and d["roofline_cg"]["frac_moved_of_hbm_peak"] <= d["roofline_cg"]["frac_of_hbm_peak"]
     assert d["host_setup_s"] > 0 and d["config"]["exchange_schedule"] == "none (one rank)"
+    assert d["post_processing"]["completed"] is True and d["post_processing"]["stage_reached"] is None
     return d
 
 
@@ -91,3 +92,18 @@ def test_bench_under_the_distributed_launcher_one_rank():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 4 and "cpu_baseline" not in d
+
+
+def test_bench_watchdog_prints_the_line_when_the_reporting_legs_overrun():
+    """the legs behind the timed region (sustained solves, exchange A/B, copy stream, traffic passes, CPU baseline) run under a watchdog: when they take longer than
+    --post-budget the line is printed with what is there and the process exits 0 -- a hang in a diagnostic leg must not cost a run its measurement"""
+    r = subprocess.run([sys.executable, BENCH, "--cells", "24", "24", "24", "--steps", "5", "--warmup", "1", "--sustained-iters", "20000", "--sustained-reps", "100",
+                        "--post-budget", "2"], capture_output=True, text=True, timeout=900, cwd=bp5_pkg.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["steps"] == 5 and d["roofline"]["achieved"] > 0 and d["roofline"]["frac"] > 0
+    assert d["post_processing"]["completed"] is False and d["post_processing"]["stage_reached"] == "sustained solves"
+    assert "cpu_baseline" not in d and "sustained" not in d and d["roofline_cg"]["stream_copy_GBs"] is None
+    assert "post-processing exceeded" in r.stderr
