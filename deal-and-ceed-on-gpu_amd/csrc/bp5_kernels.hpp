@@ -1309,7 +1309,12 @@ struct BlockPass {
   static __device__ __forceinline__ void tile_sync()
   {
     if constexpr (WAVE_LOCAL) team_sync<1>();
-    else __syncthreads();
+    else {
+      // explicit drain (see lds_drain()): with alternating tiles a tile is rewritten one barrier after its reads -- reads and writes of
+      // every wave must have left the LDS queue when the wave arrives (the fence of __syncthreads() asks for the same wait)
+      if constexpr (PP) lds_drain();
+      __syncthreads();
+    }
   }
   // the barrier behind the READS of a tile (write-after-read): not needed between alternating tiles
   static __device__ __forceinline__ void tile_sync_r()
