@@ -734,6 +734,26 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int w
     const uint32_t tile1 = window == COMBINE_OWNED ? (dp->n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE : all_tiles;
     cr.dof_lo = window == COMBINE_GHOST ? mf->n_owned : 0u;
     cr.dof_hi = window == COMBINE_OWNED ? mf->n_owned : 0xffffffffu;
+    if (window == COMBINE_GHOST_THEN_OWNED) {
+      // owned rows exactly as COMBINE_OWNED (tiles, columns), preceded in the SAME launch by one workgroup per ghost tile that signals
+      if (!(mf->fuse.on && set && mf->d_signal)) return fail(BP5_ERR_INVALID, "ghost-rows-first combine launch: fused overwrite launches with a signal word only");
+      cr.tile0 = 0u;
+      cr.dof_lo = 0u; cr.dof_hi = mf->n_owned;
+      cr.ghost_tile0 = dp->n_shared_owned / COMBINE_TILE;
+      cr.ghost_blocks = all_tiles - cr.ghost_tile0;
+      cr.signal = mf->d_signal;
+      const uint32_t owned_tiles = (dp->n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE;
+      cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
+      cr.n_owned = mf->n_owned; cr.n_tiles = owned_tiles; cr.cg_state = mf->d_st;
+      if (mf->fuse.n_cols + 1024u + 8u > (uint32_t)PARTIAL_STRIDE) return fail(BP5_ERR_UNSUPPORTED, "no partial-sum columns left for the combine pass");
+      const uint32_t grid = std::min<uint32_t>(owned_tiles, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u);
+      if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      else hipLaunchKernelGGL((combine_runs_kernel<false, true, false>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      KERNEL_CHECK();
+      mf->fuse.n_cols += grid;
+      mf->signal_target += cr.ghost_blocks; // every ghost workgroup counts itself in once
+      return BP5_OK;
+    }
     if (tile1 <= cr.tile0) return BP5_OK; // no row in the window
     const dim3 cgt(tile1 - cr.tile0);
     if (mf->fuse.on && window != COMBINE_GHOST) { // fused CG dot products over the brick-surface DoFs; columns behind the block kernel's workgroups
@@ -1488,9 +1508,24 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
       if (st == BP5_OK) st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
       mf->defer_combine = false;
       if (st == BP5_OK) st = prof.mark(2);
-      if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
-      if (st == BP5_OK) st = scatter_exchange(mf, dst, true);
-      if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, mf->n_ghost ? COMBINE_OWNED : COMBINE_ALL);
+      // BP5_COMBINE_SIGNAL=1 (A/B knob for tools and tests, read per application): the two combine launches as ONE -- its first workgroups
+      // complete the ghost rows and count themselves in, the communication stream waits for the count (stream wait-value) and starts the
+      // exchange while the same launch walks the owned rows; same tiles and columns as the two launches: same bits.  One launch, one gap and
+      // one cross-stream event less -- and on ONE GPU 16 us per iteration SLOWER than the two launches (0.547 against 0.531 ms on the slab of
+      // rank 3 of 8, profiles/r3 z_*: the RCCL kernel then runs beside the bandwidth-bound combine pass from its first microsecond and both
+      // crawl), hence not the default; whether a longer xGMI transfer pays for the earlier start is for a multi-GPU run to say
+      const bool combine_signal = [] { const char *e = getenv("BP5_COMBINE_SIGNAL"); return e && e[0] == '1'; }();
+      const bool one_combine = combine_signal && mf->can_wait_value == 1 && mf->n_ghost && mf->d_signal && dp && dp->n_shared > dp->n_shared_owned && dp->cr_tile && !mf->combine_csr; // (ghost rows among the shared ones: at least one workgroup signals)
+      if (one_combine) {
+        if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST_THEN_OWNED);
+        if (st == BP5_OK && hipStreamWaitValue64(mf->comm_stream, mf->d_signal, mf->signal_target, hipStreamWaitValueGte, ~0ull) != hipSuccess)
+          st = fail(BP5_ERR_HIP, "hipStreamWaitValue64");
+        if (st == BP5_OK) st = scatter_exchange(mf, dst, true, true);
+      } else {
+        if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+        if (st == BP5_OK) st = scatter_exchange(mf, dst, true);
+        if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, mf->n_ghost ? COMBINE_OWNED : COMBINE_ALL);
+      }
       if (st == BP5_OK) st = prof.mark(3);
       if (prof.on) prof.used += 4;
       if (st == BP5_OK) st = phase_mark(mf, 3);

@@ -195,7 +195,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block =
 int get_plan(bp5_mf *mf, int cpt, bp5::TeamPlan &tp, bp5_mf::DevPlan **dpo);
 // window: COMBINE_ALL every shared row; COMBINE_GHOST / COMBINE_OWNED only the rows of ghost / owned DoFs (the boundary-first exchange
 // schedule completes the ghost rows before the interior bricks run); the windows need the run-length form of the pass
-enum { COMBINE_ALL = 0, COMBINE_GHOST = 1, COMBINE_OWNED = 2 };
+enum { COMBINE_ALL = 0, COMBINE_GHOST = 1, COMBINE_OWNED = 2, COMBINE_GHOST_THEN_OWNED = 3 }; // 3: one launch, ghost rows first + signal (fused solves)
 int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window = COMBINE_ALL);
 // [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
 bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1);

@@ -2591,6 +2591,12 @@ struct CombineRuns {
   double *dot_partials;    // [7][PARTIAL_STRIDE]; this launch writes the columns [dot_col0, dot_col0 + gridDim.x)
   uint32_t dot_col0, n_owned, n_tiles;
   const int *cg_state;
+  // DOTS builds, exchange under the owned-row combine in ONE launch: the first ghost_blocks workgroups complete the GHOST rows (tile
+  // ghost_tile0 + blockIdx.x, DoFs >= n_owned, the plain sum: ghost rows never enter the dot products and keep no Dirichlet copy), release
+  // their stores and count themselves in at *signal -- the communication stream waits for the count (hipStreamWaitValue64) and sends the
+  // rows while the remaining workgroups walk the owned rows exactly as a launch of their own would (same tiles, same columns: same bits)
+  uint32_t ghost_blocks, ghost_tile0;
+  unsigned long long *signal;
 };
 constexpr int COMBINE_TILE = 512; // shared-DoF ordinals per tile: 256 threads x two ordinals
 // PAIR: a thread takes two CONSECUTIVE ordinals (16-byte slab loads when both lie in one run): 1 % of a CG iteration at 1e8 DoFs;
@@ -2602,10 +2608,26 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
   __shared__ uint32_t s_start[COMBINE_TILE + 2], s_dof0[COMBINE_TILE + 1], s_soff[COMBINE_TILE + 2];
   __shared__ double s_red[4][4];
   double ds[4] = {0.0, 0.0, 0.0, 0.0};
-  if constexpr (DOTS) { if (cr.cg_state[0]) return; }
+  const bool ghost_job = DOTS && blockIdx.x < cr.ghost_blocks;                       // (workgroup-uniform)
+  const uint32_t bid = blockIdx.x - (DOTS ? cr.ghost_blocks : 0u), nblk = gridDim.x - (DOTS ? cr.ghost_blocks : 0u);
+  auto ghost_rows_done = [&](bool stores_pending) { // as apply_block_kernel's signal_part_done
+    if (stores_pending) __syncthreads();
+    if (threadIdx.x == 0) {
+      if (stores_pending) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(cr.signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if constexpr (DOTS) {
+    if (cr.cg_state[0]) { // the solve has stopped: a no-op launch -- whoever waits for the ghost rows must still be released
+      if (ghost_job) ghost_rows_done(false);
+      return;
+    }
+  }
+  const uint32_t dof_lo = ghost_job ? cr.n_owned : cr.dof_lo, dof_hi = ghost_job ? 0xffffffffu : cr.dof_hi;
   // one value: sum of its partials in ascending group order; Dirichlet rows of the fused build store p instead; dot products
   auto finish = [&](uint32_t g, bool dirichlet, double s) {
-    if (g < cr.dof_lo || g >= cr.dof_hi) return; // another launch's row
+    if (g < dof_lo || g >= dof_hi) return; // another launch's (or job's) row
+    if (ghost_job) { dst[g] = s; return; }  // (what combine_runs_kernel<false, false> stores: a ghost row)
     if constexpr (DOTS) {
       double vi = s;
       if (dirichlet) { // v = p (copy_constrained_values, bp5/step-64.cu:275); p.v correction as in the block kernel
@@ -2651,7 +2673,9 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
     }
     return sum;
   };
-  for (uint32_t tile = cr.tile0 + blockIdx.x; tile < (DOTS ? cr.tile0 + cr.n_tiles : cr.tile0 + blockIdx.x + 1); tile += gridDim.x) {
+  const uint32_t t_begin = ghost_job ? cr.ghost_tile0 + blockIdx.x : cr.tile0 + bid;
+  const uint32_t t_end = ghost_job ? t_begin + 1 : (DOTS ? cr.tile0 + cr.n_tiles : cr.tile0 + blockIdx.x + 1);
+  for (uint32_t tile = t_begin; tile < t_end; tile += (nblk ? nblk : 1u)) {
     if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
     const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= COMBINE_TILE
     const uint32_t cnt = r_hi - r_lo + 1;
@@ -2700,6 +2724,7 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
     }
   }
   if constexpr (DOTS) {
+    if (ghost_job) { ghost_rows_done(true); return; } // (no column: ghost rows never enter the dot products)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2711,7 +2736,7 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
     __syncthreads();
     if (threadIdx.x < 7) {
       const int t = threadIdx.x, k = t < 4 ? t : (t == 4 ? 2 : t == 5 ? 1 : 3); // D == 1
-      cr.dot_partials[t * PARTIAL_STRIDE + cr.dot_col0 + blockIdx.x] = (s_red[k][0] + s_red[k][1]) + (s_red[k][2] + s_red[k][3]);
+      cr.dot_partials[t * PARTIAL_STRIDE + cr.dot_col0 + bid] = (s_red[k][0] + s_red[k][1]) + (s_red[k][2] + s_red[k][3]);
     }
   }
 }

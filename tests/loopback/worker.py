@@ -82,6 +82,9 @@ def main():
         solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_late_gather")
         solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped_late_gather")
         del os.environ["BP5_EARLY_GATHER"]
+        os.environ["BP5_COMBINE_SIGNAL"] = "1"     # the default schedule with ONE combine launch (ghost rows first, stream wait-value): the same bits
+        solve(pkg.SolverCGFullMerge, 2, True, "merged_default_one_combine_launch")
+        del os.environ["BP5_COMBINE_SIGNAL"]
         res["norms"] = np.asarray(norms)
         # Jacobi-preconditioned merged CG (diagonal assembled across ranks)
         op.mf_data.set_overlap(2)

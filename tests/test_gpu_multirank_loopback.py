@@ -95,7 +95,7 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
     x_merged, _, res_merged = O.cg_merged(pr.vmult, b_ref, iters)
     assert _rel(full["x_plain"], x_plain) < 1e-11 and _rel(full["x_plain_overlapped"], x_plain) < 1e-11
     merged = ["merged_unsplit", "merged_overlapped", "merged_default", "merged_unfused", "merged_unsplit_again", "merged_overlapped_again",
-              "merged_unsplit_late_gather", "merged_overlapped_late_gather"]
+              "merged_unsplit_late_gather", "merged_overlapped_late_gather", "merged_default_one_combine_launch"]
     for k in merged:
         assert _rel(full["x_" + k], x_merged) < 1e-11, k
     on_block_kernel = int(ranks[0]["variant"]) == 56
@@ -109,6 +109,8 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
         # same arithmetic, explicit fma) or after it (BP5_EARLY_GATHER=0): the same bits
         assert np.array_equal(full["x_merged_unsplit_late_gather"], full["x_merged_unsplit"])
         assert np.array_equal(full["x_merged_overlapped_late_gather"], full["x_merged_unsplit"])
+        # BP5_COMBINE_SIGNAL=1: ghost rows and owned rows of the combine pass in ONE launch, the exchange released by a stream wait-value
+        assert np.array_equal(full["x_merged_default_one_combine_launch"], full["x_merged_unsplit"])
     for z in ranks:
         # block kernel: the dot products stay fused in BOTH exchange schedules (1 unsplit, 2 boundary-first); atomic kernels: 3-phase split
         assert bool(z["fused_merged_unsplit"]) == on_block_kernel and bool(z["fused_merged_overlapped"]) == on_block_kernel and not bool(z["fused_merged_unfused"])
