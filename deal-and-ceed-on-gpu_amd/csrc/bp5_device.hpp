@@ -561,6 +561,10 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
         bp5_mf::DevPlan *dp_ = nullptr;
         BP5_TRY(get_plan_raw(mf, -(256 / LPCB), &dp_));
         if (!dp_->packed) return fail(BP5_ERR_UNSUPPORTED, "variant 56 needs packed indices (<= 128 runs per cell block)");
+        if constexpr (DEG == 4) if (!coll_ && streaming_accesses(mf)) { // streaming policy (non-temporal metric loads on small meshes), as for conforming meshes
+          if (mf->fuse.on) return launch_block_t<4, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HANG + 32768>(mf, coef, src, dst, overwrite);
+          return launch_block_t<4, false, LPCB, 2048 + 8192 + 16384 + 262144 + HANG + 32768>(mf, coef, src, dst, overwrite);
+        }
         if (mf->fuse.on)
           return coll_ ? launch_block_t<DEG, true, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HANG>(mf, coef, src, dst, overwrite)
                        : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + 1048576 + HANG>(mf, coef, src, dst, overwrite);
