@@ -389,6 +389,11 @@ def main():
                        "cg_dot_products_fused_on_every_rank": fused_all, "cg_dot_products_fused_on_some_rank": fused_any,
                        "exchange_schedule": SCHEDULES.get(ctl.exchange_schedule, "?"), "overlap_policy": args.overlap},
             "value_per_gpu": value / world,   # the reference's convention divides by the rank count (bp5/step-64.cu:457-461)
+            # the all-reduced residual norms of the TIMED solve (x0 = 0, exactly `steps` iterations): the same problem at every N, so the lines of an
+            # N = 1, 2, 4, 8 sweep must agree in these to rounding (the partition only changes summation orders) -- parity across ranks on the
+            # hardware the sweep runs on, for free
+            "solve_check": {"initial_residual": ctl.initial_value(), "residual_after_timed_solve": ctl.last_value(), "iterations": iters,
+                            "note": "strong scaling: identical across N up to rounding (relative 1e-10)"},
             "host_setup_s": setup_s,          # this rank: mesh generation, index plans, upload, merged metric, RHS (every rank does its own slab in parallel)
             # whole iteration against the roofline, priced by the CONTRACT FORMULA of SURVEY 8(d) (16 + 4r + 48r + 88 B/DoF): a formula-based
             # figure, not a measured bandwidth -- the fused iteration moves fewer bytes than the formula credits (2r index stream, 8 B instead

@@ -37,6 +37,8 @@ def _check(line, steps, warmup):
     assert "contract formula" in d["roofline_cg"]["basis"] and d["roofline_cg"]["frac_moved_of_hbm_peak"] <= d["roofline_cg"]["frac_of_hbm_peak"]
     assert d["host_setup_s"] > 0 and d["config"]["exchange_schedule"] == "none (one rank)"
     assert d["post_processing"]["completed"] is True and d["post_processing"]["stage_reached"] is None
+    sc = d["solve_check"]
+    assert sc["iterations"] == steps and sc["residual_after_timed_solve"] > 0 and sc["initial_residual"] > 0
     return d
 
 

@@ -170,6 +170,17 @@ def test_bench_with_two_ranks_as_the_driver_launches_it():
         for k in ("update", "gather_wait", "operator", "exchange", "reduce_local", "allreduce", "control", "iteration"):
             assert e["phases_ms_max_over_ranks"][k] >= e["phases_ms_min_over_ranks"][k] >= 0.0
         assert e["phases_ms_max_over_ranks"]["operator"] > 0 and e["phases_ms_max_over_ranks"]["iteration"] > 0
+    # solve_check: the all-reduced residual norms of the timed solve are those of the SAME problem on one rank (what lets the lines of an
+    # N = 1, 2, 4, 8 sweep vouch for each other)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cells", "16", "16", "16",
+                          "--sustained-iters", "0", "--apply-variant", "56", "--no-cpu-baseline", "--no-traffic-pass"],
+                         env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])["solve_check"]
+    got = out["solve_check"]
+    assert got["iterations"] == ref["iterations"] == 6
+    assert abs(got["initial_residual"] - ref["initial_residual"]) <= 1e-12 * ref["initial_residual"]
+    assert abs(got["residual_after_timed_solve"] - ref["residual_after_timed_solve"]) <= 1e-10 * ref["residual_after_timed_solve"]
 
 
 @pytest.mark.parametrize("world,p,amp", [(2, 2, 0.03), (3, 3, 0.0), (2, 4, 0.02)])
