@@ -335,6 +335,7 @@ def main():
     extras = {"stage": "sustained solves", "fused_all": bool(ctl.dot_products_fused), "fused_any": bool(ctl.dot_products_fused)}
     post_budget = args.post_budget if args.post_budget is not None else (600.0 if world == 1 else 240.0)
     compose_ref, printed = [], threading.Lock()
+    apply_variant_used = op.mf_data.get_apply_variant()   # (read here: compose() may run on the watchdog thread and must not enter the library)
 
     def watchdog_fire():
         if rank == 0 and compose_ref and printed.acquire(blocking=False):
@@ -353,8 +354,7 @@ def main():
         B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
         B_op = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G, operator_only=True)
         apply_s = ctl.apply_ms_avg * 1e-3
-        ev = op.mf_data.get_apply_variant()
-        key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}" + ("_helmholtz" if args.operator == "helmholtz" else "")
+        ev = apply_variant_used
         block_kernel = ctl.apply_kernel.startswith("apply_block_kernel")
         # SolverCGFullMerge on the packed block kernel: the dot products of update_b (contract: "dot reads p,r,v",
         # 24 B/DoF of the formula's 88) are formed inside the operator's write-out (reported by the solve itself)
@@ -564,7 +564,7 @@ def main():
 
     if rank == 0:
         extras["stage"] = "HBM traffic passes (rocprofv3 --pmc children)"
-        ev = op.mf_data.get_apply_variant()
+        ev = apply_variant_used
         key = f"p{p}_{args.quadrature}_{base[0]}x{base[1]}x{base[2]}_{args.geometry}_v{ev}" + ("_helmholtz" if args.operator == "helmholtz" else "")
         kname = ctl.apply_kernel or f"apply variant {ev}"
         tr = None
