@@ -91,6 +91,33 @@ def test_cell_loop_all_degrees(p, quad):
     assert rel(dst.cpu().numpy(), ref) < TOL_OP
 
 
+@pytest.mark.parametrize("p,bricks", [(1, False), (2, False), (3, False), (4, False), (4, True), (6, True), (8, False)])
+def test_cell_loop_against_closed_form_element_matrices(p, bricks):
+    """The HIP path against matrices that do not come from the oracle: on affine cubes of edge h (coefficient 1, Gauss(p+1) quadrature) the
+    cell operator is h (K x M x M + M x K x M + M x M x K) with the textbook 1-D stiffness / mass matrices of the GLL Lagrange basis
+    (tests/test_oracle_known_answers.py::_textbook_1d: rational matrices for p = 1, 2, 40-digit polynomial algebra above) -- geometry kernel,
+    merged metric, tables and the fused operator kernel (pencil kernel, or the block kernel on bricks) end to end, through the mesh's own
+    local_to_global"""
+    from test_oracle_known_answers import _textbook_1d
+    K, M = _textbook_1d(p)
+    cells, h = ((4, 4, 2), 0.25) if bricks else ((3, 2, 2), 0.5)
+    kw = dict(cell_block=(4, 4, 2) if p == 4 else (4, 4, 2), dof_numbering=1, cell_block_order=1) if bricks else {}
+    mesh = pkg.BrickMesh(p, cells, h=h, **kw)
+    mf = pkg.MatrixFree().reinit(mesh, pkg.QUAD_GAUSS, pkg.COEF_ONE)
+    if bricks:
+        mf.set_apply_variant(56)
+    coef = mf.evaluate_coefficients()
+    s = O.deterministic_src(mesh.n_owned, seed=11)
+    dst = mf.initialize_dof_vector()
+    mf.cell_loop(coef, dev(s), dst)
+    Ae = h * (np.kron(M, np.kron(M, K)) + np.kron(M, np.kron(K, M)) + np.kron(K, np.kron(M, M)))
+    ref = np.zeros(mesh.n_owned)
+    l2g = np.asarray(mesh.l2g).reshape(mesh.n_cells, -1).astype(np.int64)
+    for c in range(mesh.n_cells):
+        np.add.at(ref, l2g[c], Ae @ s[l2g[c]])
+    assert rel(dst.cpu().numpy(), ref) < 1e-12
+
+
 @pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1),
                                        (1, 10), (2, 10), (3, 10), (4, 10), (4, 11), (4, 12), (4, 13), (5, 10), (6, 10), (7, 10), (8, 10),
                                        (1, 50), (2, 50), (3, 50), (4, 50), (4, 51), (5, 50), (6, 50), (7, 50), (8, 50), (4, 110), (4, 52), (4, 53), (4, 54), (4, 55)])

@@ -493,3 +493,75 @@ def test_operator_diagonal_with_hanging_nodes_is_the_diagonal_of_the_assembled_o
         ref[g] = O.apply_cells(m, coef, N, D, e)[g]
     ref[m.constrained.astype(np.int64)] = 1.0
     assert np.abs(d - ref).max() < 1e-13 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------ closed-form element matrices (an anchor outside the oracle's own tables)
+def _textbook_1d(p):
+    """stiffness (u', v') and mass (u, v) of the Lagrange basis on the GLL nodes of [0, 1]: p = 1, 2 are the rational matrices of every
+    FEM text (linear: [[1,-1],[-1,1]], 1/6 [[2,1],[1,2]]; quadratic: 1/3 [[7,-8,1],[-8,16,-8],[1,-8,7]], 1/30 [[4,2,-1],[2,16,2],[-1,2,4]]);
+    higher degrees by exact (power-rule) integration in 40-digit arithmetic of the Lagrange polynomials through the GLL nodes, themselves the
+    roots of (1 - x^2) P_p'(x) from the exact rational coefficients of the Legendre polynomial -- nothing here uses the oracle's tables, quadrature rules or metric code"""
+    if p == 1:
+        return np.array([[1.0, -1.0], [-1.0, 1.0]]), np.array([[2.0, 1.0], [1.0, 2.0]]) / 6.0
+    if p == 2:
+        return (np.array([[7.0, -8.0, 1.0], [-8.0, 16.0, -8.0], [1.0, -8.0, 7.0]]) / 3.0,
+                np.array([[4.0, 2.0, -1.0], [2.0, 16.0, 2.0], [-1.0, 2.0, 4.0]]) / 30.0)
+    import mpmath as mp
+    import sympy as sy
+    mp.mp.dps = 40
+    x = sy.symbols("x")
+    dP = sy.Poly(sy.diff(sy.legendre(p, x), x), x)                     # exact rational coefficients
+    inner = sorted(mp.polyroots([mp.mpf(sy.Rational(c).p) / mp.mpf(sy.Rational(c).q) for c in dP.all_coeffs()], maxsteps=200, extraprec=200), key=lambda r: mp.re(r))
+    nodes = [mp.mpf(0)] + [(1 + mp.re(r)) / 2 for r in inner] + [mp.mpf(1)]   # GLL nodes on [0, 1] to 40 digits
+    assert len(nodes) == p + 1
+
+    def mul(a, b):                                                          # polynomial product, coefficients low -> high
+        c = [mp.mpf(0)] * (len(a) + len(b) - 1)
+        for i, ai in enumerate(a):
+            for j, bj in enumerate(b):
+                c[i + j] += ai * bj
+        return c
+    ell = []
+    for i in range(p + 1):
+        c = [mp.mpf(1)]
+        for j in range(p + 1):
+            if j != i:
+                c = mul(c, [-nodes[j] / (nodes[i] - nodes[j]), 1 / (nodes[i] - nodes[j])])
+        ell.append(c)
+    der = lambda c: [k * c[k] for k in range(1, len(c))]
+    integ01 = lambda c: sum(ck / (k + 1) for k, ck in enumerate(c))        # exact integral over [0, 1] by the power rule
+    K = np.array([[float(integ01(mul(der(ell[i]), der(ell[j])))) for j in range(p + 1)] for i in range(p + 1)])
+    M = np.array([[float(integ01(mul(ell[i], ell[j]))) for j in range(p + 1)] for i in range(p + 1)])
+    return K, M
+
+
+@pytest.mark.parametrize("p,h", [(1, 1.0), (2, 0.5), (3, 0.25), (4, 2.0), (6, 1.0), (8, 0.5)])
+def test_cell_operator_against_closed_form_element_matrices(p, h):
+    """On an affine cube of edge h (constant coefficient 1, Gauss(p+1) quadrature: exact there) the cell operator is
+    h (K x M x M + M x K x M + M x M x K) with the 1-D stiffness / mass matrices of the unit interval, local index i + n (j + n k)
+    (bp5/fe_evaluation_gl.h:139-142).  Pins tables, quadrature, metric (JxW K K^T, plane order bp5/step-64.cu:107-113) and the cell
+    operator end to end against matrices that do not come from the oracle; the RHS b_i = int phi_i (bp5/step-64.cu:401-405) and the
+    Helmholtz mass term against the same M."""
+    K, M = _textbook_1d(p)
+    pr = O.Problem(p, (1, 1, 1), O.QUAD_GAUSS, h=h)
+    Ae = O.element_matrix(pr.coef[:, 0], pr.N, pr.D)
+    ref = h * (np.kron(M, np.kron(M, K)) + np.kron(M, np.kron(K, M)) + np.kron(K, np.kron(M, M)))
+    assert np.linalg.norm(Ae - ref) < 1e-12 * np.linalg.norm(ref)
+    # the operator through the sum-factorised path, unconstrained part: A s over the one-cell mesh (all DoFs of a one-cell mesh lie on
+    # the boundary, so compare the cell loop itself)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=3)
+    got = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)
+    idx = pr.mesh.l2g[0].astype(np.int64)
+    want = np.zeros_like(s)
+    np.add.at(want, idx, ref @ s[idx])
+    assert np.linalg.norm(got - want) < 1e-12 * np.linalg.norm(want)
+    # int phi_i = row sums of the 3-D mass matrix
+    m3 = h ** 3 * np.kron(M, np.kron(M, M))
+    pr2 = O.Problem(p, (2, 2, 2), O.QUAD_GAUSS, h=h)
+    b = pr2.rhs()
+    # (Dirichlet rows of b are zero; the only interior DoFs of a 2x2x2 mesh that touch all eight cells... compare cell by cell instead)
+    bc = np.zeros(pr2.mesh.n_dofs)
+    for c in range(pr2.mesh.n_cells):
+        np.add.at(bc, pr2.mesh.l2g[c].astype(np.int64), m3.sum(axis=1))
+    bc[pr2.mesh.constrained.astype(np.int64)] = 0.0
+    assert np.linalg.norm(b - bc) < 1e-12 * np.linalg.norm(bc)
