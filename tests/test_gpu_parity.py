@@ -776,6 +776,25 @@ def test_config1_cg_plain_and_merged():
         assert abs(ctl.initial_value() - np.linalg.norm(z["b"])) < 1e-12 * np.linalg.norm(z["b"])
 
 
+def test_config1_solution_against_textbook_matrices():
+    """BASELINE config 1 on the HIP path against a solve that shares no code with the oracle (global operator from the rational quadratic
+    element matrices of every FEM text, CG written out in numpy: tests/test_oracle_known_answers.py::config1_from_textbook_matrices):
+    solution vector within the north-star tolerance 1e-11, plain and merged solver, matched DoF by DoF through the node coordinates."""
+    from test_oracle_known_answers import config1_from_textbook_matrices
+    x_ref, res = config1_from_textbook_matrices(10)
+    mesh = pkg.BrickMesh(2, (8, 8, 8))
+    ijk = np.rint(np.asarray(mesh.coords).reshape(-1, 3)[:mesh.n_owned] * 2.0).astype(int)
+    ref = x_ref[ijk[:, 2], ijk[:, 1], ijk[:, 0]]
+    op = pkg.PoissonOperator(mesh, pkg.QUAD_GAUSS)
+    b = op.assemble_rhs()
+    for solver in (pkg.SolverCG, pkg.SolverCGFullMerge):
+        x = op.initialize_dof_vector()
+        ctl = pkg.IterationNumberControl(10, 0.0)
+        solver(ctl).solve(op, x, b, pkg.DiagonalMatrix())
+        assert ctl.last_step() == 10 and rel(x.cpu().numpy(), ref) < TOL_CG
+        assert abs(ctl.initial_value() - res[0]) < 1e-12 * res[0] and abs(ctl.last_value() - res[-1]) < 1e-8 * res[-1]
+
+
 @pytest.mark.parametrize("iters", [1, 2, 3, 4, 7, 8])
 def test_merged_cg_epilogue_parity(iters):
     """The merged solver's deferred x update must reproduce plain CG at every stopping parity

@@ -565,3 +565,60 @@ def test_cell_operator_against_closed_form_element_matrices(p, h):
         np.add.at(bc, pr2.mesh.l2g[c].astype(np.int64), m3.sum(axis=1))
     bc[pr2.mesh.constrained.astype(np.int64)] = 0.0
     assert np.linalg.norm(b - bc) < 1e-12 * np.linalg.norm(bc)
+
+
+def config1_from_textbook_matrices(iters=10):
+    """BASELINE config 1 (p = 2, 8^3 unit cells as in bp5/step-64.cu:656-663, 4913 DoFs, zero Dirichlet
+    values on the boundary, b_i = int phi_i, x0 = 0, `iters` steps of textbook CG) WITHOUT the oracle: global operator from the rational
+    quadratic element matrices of _textbook_1d(2) on a lexicographic node grid, Dirichlet rows as in PoissonOperator::vmult
+    (bp5/step-64.cu:263-276: dst[c] = src[c]), Hestenes-Stiefel CG written out here.  Returns (x on the (17, 17, 17) node grid, residual norms)."""
+    K, M = _textbook_1d(2)
+    nc, h, n1 = 8, 1.0, 17
+    Ae = h * (np.kron(M, np.kron(M, K)) + np.kron(M, np.kron(K, M)) + np.kron(K, np.kron(M, M)))
+    be = h ** 3 * np.kron(M, np.kron(M, M)).sum(axis=1)
+    node = lambda I, J, Kk: I + n1 * (J + n1 * Kk)
+    loc = np.array([[node(2 * cx + i, 2 * cy + j, 2 * cz + k) for k in range(3) for j in range(3) for i in range(3)]
+                    for cz in range(nc) for cy in range(nc) for cx in range(nc)])            # local index i + 3 (j + 3 k)
+    g = np.arange(n1)
+    I, J, Kk = np.meshgrid(g, g, g, indexing="ij")
+    bnd = np.zeros(n1 ** 3, bool)
+    bnd[node(I, J, Kk)[(I == 0) | (I == n1 - 1) | (J == 0) | (J == n1 - 1) | (Kk == 0) | (Kk == n1 - 1)]] = True
+
+    def A(v):
+        w = np.where(bnd, 0.0, v)
+        out = np.zeros_like(v)
+        np.add.at(out, loc.ravel(), (w[loc] @ Ae.T).ravel())
+        out[bnd] = v[bnd]
+        return out
+    b = np.zeros(n1 ** 3)
+    np.add.at(b, loc.ravel(), np.tile(be, len(loc)))
+    b[bnd] = 0.0
+    x = np.zeros_like(b)
+    r = b.copy()
+    d = r.copy()
+    rr = r @ r
+    res = [np.sqrt(rr)]
+    for _ in range(iters):
+        q = A(d)
+        alpha = rr / (d @ q)
+        x += alpha * d
+        r -= alpha * q
+        rr_new = r @ r
+        d = r + (rr_new / rr) * d
+        rr = rr_new
+        res.append(np.sqrt(rr))
+    return x.reshape(n1, n1, n1), np.array(res)      # [K][J][I]
+
+
+def test_config1_solution_against_textbook_matrices():
+    """The oracle's config-1 solve (plain and merged CG, 10 iterations) against a solve that shares no code with it: solution within the
+    north-star tolerance 1e-11 (the two differ in summation orders only), DoF by DoF through the node coordinates."""
+    x_ref, res = config1_from_textbook_matrices(10)
+    pr = O.Problem(2, (8, 8, 8), O.QUAD_GAUSS)
+    m = pr.mesh
+    ijk = np.rint(np.asarray(m.coords).reshape(-1, 3) * 2.0).astype(int)        # node coordinates -> grid indices (h = 1: nodes at multiples of 1/2)
+    ref = x_ref[ijk[:, 2], ijk[:, 1], ijk[:, 0]]
+    for solver in (O.cg_plain, O.cg_merged):
+        x, k, _ = solver(pr.vmult, pr.rhs(), 10)
+        assert k == 10 and np.linalg.norm(x - ref) < 1e-11 * np.linalg.norm(ref)
+    assert abs(np.linalg.norm(pr.rhs()) - res[0]) < 1e-13 * res[0]
