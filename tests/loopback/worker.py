@@ -20,6 +20,7 @@ def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     out = sys.argv[4]
     p, nx, ny, nz, bx, by, bz, numbering, iters, variant = (int(a) for a in sys.argv[5:15])
+    stop_tol = float(sys.argv[15]) if len(sys.argv) > 15 else 0.0   # > 0: additional solves that stop on this absolute residual tolerance
     assert os.environ.get("BP5_LIB", "").endswith("libbp5_loopback.so"), "this worker must run on the loopback build"
     import torch
     import torch.distributed as dist
@@ -86,6 +87,24 @@ def main():
         solve(pkg.SolverCGFullMerge, 2, True, "merged_default_one_combine_launch")
         del os.environ["BP5_COMBINE_SIGNAL"]
         res["norms"] = np.asarray(norms)
+        if stop_tol > 0.0:
+            # tolerance stop across ranks: every rank sees the same all-reduced residual, the device-side convergence flag fires on all of them in
+            # the same iteration and freezes the iterate (the host only enqueues; check_every = 3 polls now and then)
+            # (constant coefficient: the step-64 coefficient of the other solves makes CG wander for hundreds of iterations on these meshes)
+            op1 = pkg.PoissonOperator(mesh, pkg.QUAD_GAUSS, pkg.COEF_ONE, comm=comm)
+            op1.mf_data.set_apply_variant(variant)
+            b1 = op1.assemble_rhs()
+            for Solver, overlap, key in ((pkg.SolverCG, 2, "stop_plain"), (pkg.SolverCGFullMerge, 2, "stop_merged_default"),
+                                         (pkg.SolverCGFullMerge, 1, "stop_merged_overlapped"), (pkg.SolverCGFullMerge, 0, "stop_merged_unsplit")):
+                op1.mf_data.set_overlap(overlap)
+                xs_ = op1.initialize_dof_vector()
+                ctl_ = pkg.SolverControl(400, stop_tol)
+                Solver(ctl_, check_every=3).solve(op1, xs_, b1, pkg.DiagonalMatrix())
+                res["x_" + key] = xs_[:no].cpu().numpy()
+                res["its_" + key] = np.asarray(int(ctl_.last_step()))
+                res["res_" + key] = np.asarray(float(ctl_.last_value()))
+            op1.mf_data.synchronize()
+            op1.mf_data.close()
         # Jacobi-preconditioned merged CG (diagonal assembled across ranks)
         op.mf_data.set_overlap(2)
         inv_diag = op.compute_diagonal(invert=True)

@@ -59,6 +59,20 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
+def _stop_tolerance(pr, k_min=8, k_max=40):
+    """(k, tol): the first iteration k >= k_min of the oracle's plain CG whose residual undercuts every earlier one by 8 %, and a tolerance
+    half way (geometrically) between that residual and the lowest earlier one: 4 % of margin on either side, rounding (1e-13) cannot
+    move the stopping iteration"""
+    hist = []
+    O.cg_plain(pr.vmult, pr.rhs(), k_max, history=hist)
+    res = [float(np.linalg.norm(pr.rhs()))] + hist            # res[k]: after k iterations
+    for k in range(k_min, k_max + 1):
+        low = min(res[:k])
+        if res[k] < 0.92 * low:
+            return k, float(np.sqrt(res[k] * low))
+    raise AssertionError("no clear record low in the oracle's residual history")
+
+
 @pytest.mark.parametrize("world,p,cells,block,numbering,variant,delay_us", [
     (2, 4, (8, 8, 12), (4, 4, 4), 1, 56, 0),  # the bench's configuration: parity-class bricks, block kernel, fused dot products
     (2, 4, (8, 8, 12), (4, 4, 4), 1, 56, 400),  # ... with every transfer lagging 0.4 ms behind its stream (cross-stream ordering of both exchange schedules)
@@ -74,8 +88,12 @@ def _rel(a, b):
 ])
 def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells, block, numbering, variant, delay_us):
     iters = 8
-    _run_ranks(world, [p, *cells, *block, numbering, iters, variant], str(tmp_path), delay_us=delay_us)
     pr = O.Problem(p, cells, O.QUAD_GAUSS, deform_amp=0.03, kappa=O.kappa_step64)
+    # tolerance stop: a tolerance half way (geometrically) between two consecutive residuals of the oracle's own history, so that rounding
+    # cannot move the stopping iteration
+    pr1 = O.Problem(p, cells, O.QUAD_GAUSS, deform_amp=0.03)      # the tolerance-stop solves: constant coefficient (converges in tens of iterations)
+    k_stop, stop_tol = _stop_tolerance(pr1)
+    _run_ranks(world, [p, *cells, *block, numbering, iters, variant, repr(stop_tol)], str(tmp_path), delay_us=delay_us)
     nd = pr.mesh.n_dofs
     ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
     keys = [k for k in ranks[0].files if k[0] in "bAx" or k == "inv_diag"]
@@ -111,6 +129,13 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
         assert np.array_equal(full["x_merged_overlapped_late_gather"], full["x_merged_unsplit"])
         # BP5_COMBINE_SIGNAL=1: ghost rows and owned rows of the combine pass in ONE launch, the exchange released by a stream wait-value
         assert np.array_equal(full["x_merged_default_one_combine_launch"], full["x_merged_unsplit"])
+    # tolerance stop across the ranks: the same iteration as the oracle on the undivided mesh, on every rank, in every schedule; iterate frozen there
+    x_stop, k_ref, _ = O.cg_plain(pr1.vmult, pr1.rhs(), 400, tol=stop_tol)
+    assert k_ref == k_stop
+    for key in ("stop_plain", "stop_merged_default", "stop_merged_overlapped", "stop_merged_unsplit"):
+        assert all(int(z["its_" + key]) == k_ref for z in ranks), (key, [int(z["its_" + key]) for z in ranks], k_ref)
+        assert all(float(z["res_" + key]) <= stop_tol for z in ranks)
+        assert _rel(full["x_" + key], x_stop) < 1e-10, key
     for z in ranks:
         # block kernel: the dot products stay fused in BOTH exchange schedules (1 unsplit, 2 boundary-first); atomic kernels: 3-phase split
         assert bool(z["fused_merged_unsplit"]) == on_block_kernel and bool(z["fused_merged_overlapped"]) == on_block_kernel and not bool(z["fused_merged_unfused"])
