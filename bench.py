@@ -489,9 +489,14 @@ def main():
         exchange_ab = {}
         k_ab = max(10, min(args.steps, 40))
         extras["exchange_ab"] = exchange_ab   # (filled leg by leg: the watchdog reports the legs that finished)
-        for mode, name in ((0, "unsplit"), (2, "automatic"), (1, "boundary_first")):   # (the default's legs first; boundary_first needs stream wait-value)
+        # (the default's legs first; the last two need stream wait-value support)
+        for mode, name in ((0, "unsplit"), (2, "automatic"), (2, "automatic_one_combine_launch"), (1, "boundary_first")):
             extras["stage"] = f"exchange A/B leg '{name}'"
             try:
+                if name == "automatic_one_combine_launch":
+                    os.environ["BP5_COMBINE_SIGNAL"] = "1"    # read by the library per operator application (every rank sets it here, in step)
+                else:
+                    os.environ.pop("BP5_COMBINE_SIGNAL", None)
                 op.mf_data.set_overlap(mode)
                 timed_solve(3)
                 actl, adt = timed_solve(k_ab, profile=False)
@@ -508,11 +513,13 @@ def main():
                 sys.stderr.write(f"[bench rank {rank}/{world}] exchange A/B leg '{name}' (bp5_mf_set_overlap({mode})) failed: {type(e).__name__}: {e}\n")
                 exchange_ab[name] = {"error": f"{type(e).__name__}: {e}"}
                 break
+        os.environ.pop("BP5_COMBINE_SIGNAL", None)
         op.mf_data.set_overlap(args.overlap)
         exchange_ab["note"] = ("same problem, same kernels, same bits; unsplit = gather, one launch, combine, scatter-add on the compute stream; "
                                "boundary_first = ghost-touching bricks first inside the launch, ghost rows + scatter-add on the communication stream "
                                "under the interior bricks; automatic = the library's default: one launch, ghost rows combined first, scatter-add on "
-                               "the communication stream under the owned-row combine.  phases: HIP "
+                               "the communication stream under the owned-row combine; automatic_one_combine_launch = the same with ghost rows and owned rows in ONE "
+                               "combine launch, the exchange released by a stream wait-value (BP5_COMBINE_SIGNAL=1: slower on one GPU, profiles/r3 z_*).  phases: HIP "
                                "events on the solver's stream (exchange = exposed part incl. unpack; gather_wait = exposed part of the ghost "
                                "gather that travels under the vector update)")
 

@@ -189,7 +189,8 @@ def test_bench_with_two_ranks_as_the_driver_launches_it():
     assert out["roofline"]["kernel"].startswith("apply_block_kernel<4,false,32,1,")                     # the name the solve itself reports
     # the N > 1 diagnostics: both exchange schedules timed, every phase of an iteration stamped (max / min over the ranks)
     ab = out["exchange_ab"]
-    for name, sched in (("unsplit", "unsplit"), ("boundary_first", "boundary-first"), ("automatic", "under-combine")):
+    for name, sched in (("unsplit", "unsplit"), ("boundary_first", "boundary-first"), ("automatic", "under-combine"),
+                        ("automatic_one_combine_launch", "under-combine")):
         e = ab[name]
         assert e["schedule_rank0"] == sched and e["dot_products_fused_rank0"] is True and e["ms_per_iteration"] > 0
         for k in ("update", "gather_wait", "operator", "exchange", "reduce_local", "allreduce", "control", "iteration"):
