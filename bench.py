@@ -207,6 +207,15 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    # host threads of this rank's set-up (mesh generation, index plans: OpenMP in libbp5.so).  torch.distributed.run exports OMP_NUM_THREADS=1
+    # to its workers unless the caller has set it, which makes every rank build its slab on ONE core (11.6 s instead of a few for the mesh of
+    # one of two ranks): give each rank its share of the node's cores instead.  BP5_HOST_THREADS overrides; must happen before the library loads.
+    n_ranks_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BP5_HOST_THREADS"):
+        os.environ["OMP_NUM_THREADS"] = os.environ["BP5_HOST_THREADS"]
+    elif n_ranks_env > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // n_ranks_env))
+
     import bp5_pkg
     pkg = bp5_pkg.load()
 
