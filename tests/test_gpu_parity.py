@@ -118,6 +118,32 @@ def test_cell_loop_against_closed_form_element_matrices(p, bricks):
     assert rel(dst.cpu().numpy(), ref) < 1e-12
 
 
+@pytest.mark.parametrize("p,bricks", [(1, False), (2, False), (3, False), (4, False), (4, True), (6, False)])
+def test_cell_loop_on_sheared_cells_against_closed_form(p, bricks):
+    """All six planes of the merged metric (order 00, 11, 22, 01, 02, 12, bp5/step-64.cu:107-113; K = d xi / d x) on the HIP path against the
+    closed form of tests/test_oracle_known_answers.py::closed_form_cell_matrix_affine: the mesh's nodes are mapped by one affine map (shear,
+    stretch, rotation), so every cell is the same parallelepiped and Gauss(p+1) quadrature is exact -- geometry kernel, merged metric and the
+    fused operator kernels (pencil kernel; block kernel on bricks) against matrices that do not come from the oracle"""
+    from test_oracle_known_answers import AFFINE_MAP, closed_form_cell_matrix_affine
+    cells = (4, 4, 2) if bricks else (3, 2, 2)
+    kw = dict(cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1) if bricks else {}
+    mesh = pkg.BrickMesh(p, cells, h=0.5, **kw)
+    mesh.coords = np.ascontiguousarray(np.asarray(mesh.coords) @ AFFINE_MAP.T)      # (the host arrays are handed over by MatrixFree.reinit)
+    mf = pkg.MatrixFree().reinit(mesh, pkg.QUAD_GAUSS, pkg.COEF_ONE)
+    if bricks:
+        mf.set_apply_variant(56)
+    coef = mf.evaluate_coefficients()
+    s = O.deterministic_src(mesh.n_owned, seed=13)
+    dst = mf.initialize_dof_vector()
+    mf.cell_loop(coef, dev(s), dst)
+    Ae = closed_form_cell_matrix_affine(p, 0.5 * AFFINE_MAP)          # cell edge 0.5: x = (0.5 A) xi + const
+    ref = np.zeros(mesh.n_owned)
+    l2g = np.asarray(mesh.l2g).reshape(mesh.n_cells, -1).astype(np.int64)
+    for c in range(mesh.n_cells):
+        np.add.at(ref, l2g[c], Ae @ s[l2g[c]])
+    assert rel(dst.cpu().numpy(), ref) < 1e-12
+
+
 @pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1),
                                        (1, 10), (2, 10), (3, 10), (4, 10), (4, 11), (4, 12), (4, 13), (5, 10), (6, 10), (7, 10), (8, 10),
                                        (1, 50), (2, 50), (3, 50), (4, 50), (4, 51), (5, 50), (6, 50), (7, 50), (8, 50), (4, 110), (4, 52), (4, 53), (4, 54), (4, 55)])

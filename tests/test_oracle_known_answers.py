@@ -496,16 +496,18 @@ def test_operator_diagonal_with_hanging_nodes_is_the_diagonal_of_the_assembled_o
 
 
 # ------------------------------------------------------------------ closed-form element matrices (an anchor outside the oracle's own tables)
-def _textbook_1d(p):
-    """stiffness (u', v') and mass (u, v) of the Lagrange basis on the GLL nodes of [0, 1]: p = 1, 2 are the rational matrices of every
+def _textbook_1d(p, with_c=False):
+    """stiffness (u', v') and mass (u, v) of the Lagrange basis on the GLL nodes of [0, 1] (with_c: also C[i][j] = int phi_i' phi_j): p = 1, 2 are the rational matrices of every
     FEM text (linear: [[1,-1],[-1,1]], 1/6 [[2,1],[1,2]]; quadratic: 1/3 [[7,-8,1],[-8,16,-8],[1,-8,7]], 1/30 [[4,2,-1],[2,16,2],[-1,2,4]]);
     higher degrees by exact (power-rule) integration in 40-digit arithmetic of the Lagrange polynomials through the GLL nodes, themselves the
     roots of (1 - x^2) P_p'(x) from the exact rational coefficients of the Legendre polynomial -- nothing here uses the oracle's tables, quadrature rules or metric code"""
     if p == 1:
-        return np.array([[1.0, -1.0], [-1.0, 1.0]]), np.array([[2.0, 1.0], [1.0, 2.0]]) / 6.0
+        K, M, C = np.array([[1.0, -1.0], [-1.0, 1.0]]), np.array([[2.0, 1.0], [1.0, 2.0]]) / 6.0, np.array([[-0.5, -0.5], [0.5, 0.5]])
+        return (K, M, C) if with_c else (K, M)
     if p == 2:
-        return (np.array([[7.0, -8.0, 1.0], [-8.0, 16.0, -8.0], [1.0, -8.0, 7.0]]) / 3.0,
-                np.array([[4.0, 2.0, -1.0], [2.0, 16.0, 2.0], [-1.0, 2.0, 4.0]]) / 30.0)
+        K, M = np.array([[7.0, -8.0, 1.0], [-8.0, 16.0, -8.0], [1.0, -8.0, 7.0]]) / 3.0, np.array([[4.0, 2.0, -1.0], [2.0, 16.0, 2.0], [-1.0, 2.0, 4.0]]) / 30.0
+        C = np.array([[-3.0, -4.0, 1.0], [4.0, 0.0, -4.0], [-1.0, 4.0, 3.0]]) / 6.0
+        return (K, M, C) if with_c else (K, M)
     import mpmath as mp
     import sympy as sy
     mp.mp.dps = 40
@@ -532,6 +534,8 @@ def _textbook_1d(p):
     integ01 = lambda c: sum(ck / (k + 1) for k, ck in enumerate(c))        # exact integral over [0, 1] by the power rule
     K = np.array([[float(integ01(mul(der(ell[i]), der(ell[j])))) for j in range(p + 1)] for i in range(p + 1)])
     M = np.array([[float(integ01(mul(ell[i], ell[j]))) for j in range(p + 1)] for i in range(p + 1)])
+    if with_c:
+        return K, M, np.array([[float(integ01(mul(der(ell[i]), ell[j]))) for j in range(p + 1)] for i in range(p + 1)])
     return K, M
 
 
@@ -622,3 +626,34 @@ def test_config1_solution_against_textbook_matrices():
         x, k, _ = solver(pr.vmult, pr.rhs(), 10)
         assert k == 10 and np.linalg.norm(x - ref) < 1e-11 * np.linalg.norm(ref)
     assert abs(np.linalg.norm(pr.rhs()) - res[0]) < 1e-13 * res[0]
+
+
+AFFINE_MAP = np.array([[1.3, 0.4, -0.2], [0.1, 0.9, 0.5], [-0.3, 0.2, 1.1]])      # shear + stretch + a little rotation, det > 0
+
+
+def closed_form_cell_matrix_affine(p, A):
+    """cell operator on the parallelepiped x = A xi (xi in the unit cube), coefficient 1:  det A  sum_ab G_ab  int d_a phi_i d_b phi_j d xi  with
+    G = A^-1 A^-T, from the 1-D matrices K = int phi' phi', M = int phi phi, C = int phi_i' phi_j of _textbook_1d; local index i + n (j + n k)"""
+    K, M, C = _textbook_1d(p, with_c=True)
+    Ainv = np.linalg.inv(A)
+    G, det = Ainv @ Ainv.T, np.linalg.det(A)
+    k3 = lambda z, y, x: np.kron(z, np.kron(y, x))
+    T = {(0, 0): k3(M, M, K), (1, 1): k3(M, K, M), (2, 2): k3(K, M, M),
+         (0, 1): k3(M, C.T, C), (0, 2): k3(C.T, M, C), (1, 2): k3(C.T, C, M)}          # T_ab[i][j] = int d_a phi_i d_b phi_j
+    Ae = sum(G[a, a] * T[(a, a)] for a in range(3))
+    for (a, b) in ((0, 1), (0, 2), (1, 2)):
+        Ae = Ae + G[a, b] * (T[(a, b)] + T[(a, b)].T)
+    return det * Ae
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 6])
+def test_cell_operator_on_a_sheared_cell_against_closed_form(p):
+    """The full symmetric metric -- all six planes JxW (K K^T)_c in the order 00, 11, 22, 01, 02, 12 (bp5/step-64.cu:107-113), K = d xi / d x
+    (bp5/fe_evaluation_gl.h:334-343) -- against the closed form on an affinely mapped cell (shear, stretch, rotation): Gauss(p+1) is exact there"""
+    m = O.BrickMesh(p, (1, 1, 1))
+    m.coords = np.asarray(m.coords) @ AFFINE_MAP.T
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    coef = O.merged_metric(m, N, D, w)
+    Ae = O.element_matrix(coef[:, 0], N, D)
+    ref = closed_form_cell_matrix_affine(p, AFFINE_MAP)
+    assert np.linalg.norm(Ae - ref) < 1e-12 * np.linalg.norm(ref)
