@@ -539,6 +539,40 @@ def _textbook_1d(p, with_c=False):
     return K, M
 
 
+def _weighted_1d(p, c0, c1):
+    """K^w = int (c0 + c1 x) phi_i' phi_j', M^w = int (c0 + c1 x) phi_i phi_j on [0, 1] in the same 40-digit polynomial algebra (all degrees)"""
+    import mpmath as mp
+    import sympy as sy
+    mp.mp.dps = 40
+    x = sy.symbols("x")
+    if p == 1:
+        nodes = [mp.mpf(0), mp.mpf(1)]
+    else:
+        dP = sy.Poly(sy.diff(sy.legendre(p, x), x), x)
+        inner = sorted(mp.polyroots([mp.mpf(sy.Rational(c).p) / mp.mpf(sy.Rational(c).q) for c in dP.all_coeffs()], maxsteps=200, extraprec=200), key=lambda r: mp.re(r))
+        nodes = [mp.mpf(0)] + [(1 + mp.re(r)) / 2 for r in inner] + [mp.mpf(1)]
+
+    def mul(a, b):
+        c = [mp.mpf(0)] * (len(a) + len(b) - 1)
+        for i, ai in enumerate(a):
+            for j, bj in enumerate(b):
+                c[i + j] += ai * bj
+        return c
+    ell = []
+    for i in range(p + 1):
+        c = [mp.mpf(1)]
+        for j in range(p + 1):
+            if j != i:
+                c = mul(c, [-nodes[j] / (nodes[i] - nodes[j]), 1 / (nodes[i] - nodes[j])])
+        ell.append(c)
+    der = lambda c: [k * c[k] for k in range(1, len(c))] or [mp.mpf(0)]
+    integ01 = lambda c: sum(ck / (k + 1) for k, ck in enumerate(c))
+    wgt = [mp.mpf(c0), mp.mpf(c1)]
+    Kw = np.array([[float(integ01(mul(wgt, mul(der(ell[i]), der(ell[j]))))) for j in range(p + 1)] for i in range(p + 1)])
+    Mw = np.array([[float(integ01(mul(wgt, mul(ell[i], ell[j])))) for j in range(p + 1)] for i in range(p + 1)])
+    return Kw, Mw
+
+
 @pytest.mark.parametrize("p,h", [(1, 1.0), (2, 0.5), (3, 0.25), (4, 2.0), (6, 1.0), (8, 0.5)])
 def test_cell_operator_against_closed_form_element_matrices(p, h):
     """On an affine cube of edge h (constant coefficient 1, Gauss(p+1) quadrature: exact there) the cell operator is
@@ -657,3 +691,20 @@ def test_cell_operator_on_a_sheared_cell_against_closed_form(p):
     Ae = O.element_matrix(coef[:, 0], N, D)
     ref = closed_form_cell_matrix_affine(p, AFFINE_MAP)
     assert np.linalg.norm(Ae - ref) < 1e-12 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_variable_coefficient_folded_into_the_planes_against_closed_form(p):
+    """kappa(x) evaluated at the physical quadrature points and folded into the six planes (the variable coefficient of BASELINE config 2;
+    the reference folds JxW the same way, bp5/step-64.cu:107-113): for kappa = 1 + a x on a cube cell [x0, x0 + h]^3-ish the integrands stay
+    within the exactness of Gauss(p+1), so the cell matrix is h (Kw x M x M-type sums) with x-weighted 1-D matrices -- closed form"""
+    a, h = 0.7, 0.5
+    m = O.BrickMesh(p, (2, 1, 1), h=h)                                       # cell 1 starts at x0 = h
+    _, _, w, N, D = O.shape_tables(p, O.QUAD_GAUSS)
+    coef = O.merged_metric(m, N, D, w, kappa=lambda X: 1.0 + a * X[..., 0])
+    K, M = _textbook_1d(p)
+    for c, x0 in ((0, 0.0), (1, h)):
+        Kw, Mw = _weighted_1d(p, 1.0 + a * x0, a * h)                        # kappa(xi) = (1 + a x0) + a h xi on this cell
+        ref = h * (np.kron(M, np.kron(M, Kw)) + np.kron(M, np.kron(K, Mw)) + np.kron(K, np.kron(M, Mw)))
+        Ae = O.element_matrix(coef[:, c], N, D)
+        assert np.linalg.norm(Ae - ref) < 1e-12 * np.linalg.norm(ref), c
