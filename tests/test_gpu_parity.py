@@ -144,6 +144,53 @@ def test_cell_loop_on_sheared_cells_against_closed_form(p, bricks):
     assert rel(dst.cpu().numpy(), ref) < 1e-12
 
 
+@pytest.mark.parametrize("p", [2, 3, 4])
+def test_rhs_diagonal_l2_norm_and_helmholtz_against_closed_forms(p):
+    """The steps either side of the operator on affine cube cells against closed forms built from the textbook 1-D matrices (no oracle):
+    b_i = int phi_i (bp5/step-64.cu:401-405) = row sums of the mass matrix, Dirichlet rows zero; diag(A) = sum over cells of the element
+    matrix's diagonal; ||u_h||_L2 of a linear field (bp5/step-64.cu:602-616) by exact integration; step-64's Helmholtz cell operator with
+    a = 1: Laplace + h^3 M x M x M (native kernel, accumulate mode)."""
+    from test_oracle_known_answers import _textbook_1d
+    torch = _t()
+    K, M = _textbook_1d(p)
+    cells, h = (3, 2, 2), 0.5
+    mesh = pkg.BrickMesh(p, cells, h=h)
+    l2g = np.asarray(mesh.l2g).reshape(mesh.n_cells, -1).astype(np.int64)
+    con = np.zeros(mesh.n_owned, bool)
+    con[np.asarray(mesh.constrained).astype(np.int64)] = True
+    Ae = h * (np.kron(M, np.kron(M, K)) + np.kron(M, np.kron(K, M)) + np.kron(K, np.kron(M, M)))
+    M3 = h ** 3 * np.kron(M, np.kron(M, M))
+    op = pkg.PoissonOperator(mesh, pkg.QUAD_GAUSS, pkg.COEF_ONE)
+    # RHS
+    b_ref = np.zeros(mesh.n_owned)
+    for c in range(mesh.n_cells):
+        np.add.at(b_ref, l2g[c], M3.sum(axis=1))
+    b_ref[con] = 0.0
+    assert rel(op.assemble_rhs().cpu().numpy(), b_ref) < 1e-12
+    # diagonal (unconstrained rows)
+    d_ref = np.zeros(mesh.n_owned)
+    for c in range(mesh.n_cells):
+        np.add.at(d_ref, l2g[c], np.diag(Ae))
+    d = op.compute_diagonal().cpu().numpy()
+    assert np.linalg.norm((d - d_ref)[~con]) < 1e-12 * np.linalg.norm(d_ref[~con])
+    # L2 norm of u = 2x - y + z/2 + 1 on [0, 1.5] x [0, 1] x [0, 1]: exact integral of a quadratic
+    X = np.asarray(mesh.coords)[:mesh.n_owned]
+    u = 2.0 * X[:, 0] - X[:, 1] + 0.5 * X[:, 2] + 1.0
+    import sympy as sy
+    x, y, z = sy.symbols("x y z")
+    exact = float(sy.sqrt(sy.integrate((2 * x - y + z / 2 + 1) ** 2, (x, 0, sy.Rational(3, 2)), (y, 0, 1), (z, 0, 1))))
+    assert abs(op.l2_norm_solution(dev(u)) - exact) < 1e-12 * exact
+    # Helmholtz cell operator, a = 1
+    hop = pkg.HelmholtzOperator(mesh, pkg.QUAD_GAUSS, pkg.COEF_ONE)
+    s = O.deterministic_src(mesh.n_owned, seed=17)
+    acc = hop.initialize_dof_vector()
+    hop.mf_data.cell_loop(hop.coef, dev(s), acc)
+    h_ref = np.zeros(mesh.n_owned)
+    for c in range(mesh.n_cells):
+        np.add.at(h_ref, l2g[c], (Ae + M3) @ s[l2g[c]])
+    assert rel(acc.cpu().numpy(), h_ref) < 1e-12
+
+
 @pytest.mark.parametrize("p,variant", [(4, 0), (4, 1), (4, 2), (4, 3), (4, 4), (4, 5), (5, 0), (5, 1), (6, 0), (6, 1), (8, 0), (8, 1),
                                        (1, 10), (2, 10), (3, 10), (4, 10), (4, 11), (4, 12), (4, 13), (5, 10), (6, 10), (7, 10), (8, 10),
                                        (1, 50), (2, 50), (3, 50), (4, 50), (4, 51), (5, 50), (6, 50), (7, 50), (8, 50), (4, 110), (4, 52), (4, 53), (4, 54), (4, 55)])
