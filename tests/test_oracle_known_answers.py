@@ -708,3 +708,38 @@ def test_variable_coefficient_folded_into_the_planes_against_closed_form(p):
         ref = h * (np.kron(M, np.kron(M, Kw)) + np.kron(M, np.kron(K, Mw)) + np.kron(K, np.kron(M, Mw)))
         Ae = O.element_matrix(coef[:, c], N, D)
         assert np.linalg.norm(Ae - ref) < 1e-12 * np.linalg.norm(ref), c
+
+
+@pytest.mark.parametrize("p", [2, 3, 4])
+def test_rhs_diagonal_l2_norm_and_helmholtz_against_closed_forms(p):
+    """the oracle's RHS, operator diagonal, L2 norm and Helmholtz cell operator (a = 1) on affine cube cells against closed forms from the
+    textbook 1-D matrices (the GPU test of the same name checks the HIP path against the same numbers)"""
+    import sympy as sy
+    K, M = _textbook_1d(p)
+    cells, h = (3, 2, 2), 0.5
+    pr = O.Problem(p, cells, O.QUAD_GAUSS, h=h)
+    m = pr.mesh
+    l2g = m.l2g.astype(np.int64)
+    con = np.zeros(m.n_dofs, bool)
+    con[m.constrained.astype(np.int64)] = True
+    Ae = h * (np.kron(M, np.kron(M, K)) + np.kron(M, np.kron(K, M)) + np.kron(K, np.kron(M, M)))
+    M3 = h ** 3 * np.kron(M, np.kron(M, M))
+    b, d = np.zeros(m.n_dofs), np.zeros(m.n_dofs)
+    for c in range(m.n_cells):
+        np.add.at(b, l2g[c], M3.sum(axis=1))
+        np.add.at(d, l2g[c], np.diag(Ae))
+    b[con] = 0.0
+    assert np.linalg.norm(pr.rhs() - b) < 1e-13 * np.linalg.norm(b)
+    do = O.operator_diagonal(m, pr.coef, pr.N, pr.D)
+    assert np.linalg.norm((do - d)[~con]) < 1e-13 * np.linalg.norm(d[~con]) and np.all(do[con] == 1.0)
+    X = np.asarray(m.coords).reshape(-1, 3)
+    u = 2.0 * X[:, 0] - X[:, 1] + 0.5 * X[:, 2] + 1.0
+    x, y, z = sy.symbols("x y z")
+    exact = float(sy.sqrt(sy.integrate((2 * x - y + z / 2 + 1) ** 2, (x, 0, sy.Rational(3, 2)), (y, 0, 1), (z, 0, 1))))
+    assert abs(O.l2_norm_solution(m, u) - exact) < 1e-13 * exact
+    s = O.deterministic_src(m.n_dofs, seed=17)
+    href = np.zeros(m.n_dofs)
+    for c in range(m.n_cells):
+        np.add.at(href, l2g[c], (Ae + M3) @ s[l2g[c]])
+    got = O.apply_helmholtz_cells(m, pr.N, pr.D, pr.w, s, coefficient=O.kappa_none)
+    assert np.linalg.norm(got - href) < 1e-13 * np.linalg.norm(href)
