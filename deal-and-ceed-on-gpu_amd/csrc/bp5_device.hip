@@ -1780,7 +1780,8 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     }
   } else {
     // SolverCGFullMerge: g == r, d == p, h == v
-    hipLaunchKernelGGL(cgm_init_kernel, dim3(grid1), dim3(VB), 0, s, b, x, g, d, h, n, mf->d_partials);
+    // (v: the fused block kernel of a one-rank solve overwrites every entry before anything reads it; every other path keeps the zero-fill)
+    hipLaunchKernelGGL(cgm_init_kernel, dim3(grid1), dim3(VB), 0, s, b, x, g, d, h, diag, n, mf->d_partials, !(fused_dots && !dist_solve));
     hipLaunchKernelGGL(finalize_kernel<2>, dim3(2), dim3(VB), 0, s, mf->d_partials, grid1, mf->d_sc + SC_GG, (const int *)nullptr);
     KERNEL_CHECK();
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
@@ -1830,7 +1831,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
       const int mode = it == 1 ? 0 : it % 2 == 0 ? 1 : 2;
       BP5_TRY(phase_mark(mf, 0));
       if (early_gather) { BP5_TRY(gather_under_update(mode)); mf->fuse.gather_in_flight = true; }
-      launch_update(mode);
+      if (mode != 0) launch_update(mode); // (mode 0, p = -D r: written by cgm_init_kernel already)
       KERNEL_CHECK();
       BP5_TRY(phase_mark(mf, 1));
       const bool one_launch = fused && !mf->comm; // no all-reduce between the local sums and the scalar step

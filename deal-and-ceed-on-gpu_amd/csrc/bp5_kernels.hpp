@@ -3221,14 +3221,17 @@ __global__ void __launch_bounds__(FIN4_THREADS) cgm_finalize4_kernel(const doubl
 static __global__ void cgm_control_kernel(double *sc, int *st) { cgm_control_step(sc, st); }
 
 // merged init: r = -b, x = 0, partial r.r
-static __global__ void __launch_bounds__(VB) cgm_init_kernel(const double *b, double *x, double *r, double *p, double *v, size_t n,
-                                                     double *partials)
+// x = 0, r = -b, and the first search direction p = -D r right away (update_a0, solver.h:48-72: the same expression as cgm_update_one<0>, so
+// the first iteration needs no update launch); v zeroed only for operator kernels that accumulate into it (zero_v)
+static __global__ void __launch_bounds__(VB) cgm_init_kernel(const double *b, double *x, double *r, double *p, double *v, const double *diag, size_t n,
+                                                     double *partials, bool zero_v)
 {
   double acc[2] = {0.0, 0.0};
   const size_t stride = (size_t)gridDim.x * VB;
   for (size_t i = (size_t)blockIdx.x * VB + threadIdx.x; i < n; i += stride) {
-    const double ri = -b[i];
-    x[i] = 0.0; r[i] = ri; p[i] = 0.0; v[i] = 0.0;
+    const double ri = -b[i], di = diag ? diag[i] : 1.0;
+    x[i] = 0.0; r[i] = ri; p[i] = -(di * ri);
+    if (zero_v) v[i] = 0.0;
     acc[0] += ri * ri;
   }
   acc[1] = acc[0];
