@@ -179,12 +179,13 @@ def main():
     ap.add_argument("--sustained-reps", type=int, default=3, help="reference protocol: repetitions, best one reported (bp5/step-64.cu:457-463)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep-other-quadrature", action="store_true", help="--config 4: only the quadrature of --quadrature per degree (default: both, the other one under its name)")
     ap.add_argument("--no-traffic-pass", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only); the committed passes of "
                          "profiles/*/traffic.json are quoted instead.  Needed under an outer profiler.")
     ap.add_argument("--post-budget", type=float, default=None,
                     help="seconds the legs AFTER the timed region may take (sustained solves, unfused solve, exchange A/B, copy stream, traffic passes, CPU "
-                         "baseline); then the line is printed with what is there and the process exits 0 (default: 600 at N = 1, 240 at N > 1) -- a hang in a "
+                         "baseline); then the line is printed with what is there and the process exits with code 4 (default: 600 at N = 1, 240 at N > 1) -- a hang in a "
                          "diagnostic leg of the first real multi-GPU run must not cost the measurement")
     ap.add_argument("--no-exchange-ab", action="store_true",
                     help="N > 1: skip the diagnostic solves after the timed region (unsplit vs boundary-first exchange, phase stamps)")
@@ -337,11 +338,27 @@ def main():
     value = n_global * iters / dt
 
     # Everything below is reporting around the measurement above.  The legs fill `extras`; compose() (defined further down) builds the line
-    # from whatever is there.  A watchdog prints the line and ends the process (exit code 0, every rank) if the legs take longer than
-    # --post-budget: a diagnostic leg that hangs (a collective only some ranks entered, a schedule the node does not support) must not
-    # cost the run its measurement.
+    # from whatever is there.  A watchdog prints the line and ends the process (every rank, exit code 4: the measurement is on stdout, the
+    # overrun -- possibly a hung GPU leg -- shows in the run record) if the legs take longer than --post-budget: a diagnostic leg that hangs
+    # (a collective only some ranks entered, a schedule the node does not support) must not cost the run its measurement.
+    import copy
     import threading
-    extras = {"stage": "sustained solves", "fused_all": bool(ctl.dot_products_fused), "fused_any": bool(ctl.dot_products_fused)}
+
+    class Extras:
+        """what the reporting legs have produced so far; the watchdog thread composes the line from a snapshot taken under the lock (legs
+        publish finished values only: a nested list or dict is re-assigned as a copy, never mutated in place)"""
+        def __init__(self, **kw):
+            self._d, self._lock = dict(kw), threading.Lock()
+        def __setitem__(self, k, v):
+            with self._lock:
+                self._d[k] = v
+        def __getitem__(self, k):
+            with self._lock:
+                return self._d[k]
+        def snapshot(self):
+            with self._lock:
+                return copy.deepcopy(self._d)
+    extras = extras_live = Extras(stage="sustained solves", fused_all=bool(ctl.dot_products_fused), fused_any=bool(ctl.dot_products_fused))
     post_budget = args.post_budget if args.post_budget is not None else (600.0 if world == 1 else 240.0)
     compose_ref, printed = [], threading.Lock()
     apply_variant_used = op.mf_data.get_apply_variant()   # (read here: compose() may run on the watchdog thread and must not enter the library)
@@ -352,12 +369,13 @@ def main():
                 print(json.dumps(compose_ref[0](False)), flush=True)
             except Exception as e:   # noqa: BLE001
                 sys.stderr.write(f"[bench rank 0] watchdog could not compose the line: {type(e).__name__}: {e}\n")
-        sys.stderr.write(f"[bench rank {rank}/{world}] post-processing exceeded {post_budget:.0f} s in stage '{extras['stage']}': line printed without it, exiting\n")
+        sys.stderr.write(f"[bench rank {rank}/{world}] post-processing exceeded {post_budget:.0f} s in stage '{extras['stage']}': line printed without it, exiting with code 4\n")
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(4)
     watchdog = threading.Timer(post_budget, watchdog_fire)
     def compose(final):
         """the JSON line from the timed solve and whatever the later legs have put into `extras` (watchdog: final = False)"""
+        extras = extras_live.snapshot()
         n_cells_local, n_dofs_local = mesh.n_cells, mesh.n_owned
         r = n_cells_local * (p + 1) ** 3 / n_dofs_local
         B = algorithmic_bytes_per_dof(p, n_cells_local, n_dofs_local, G=G)
@@ -497,15 +515,12 @@ def main():
     if world > 1 and not args.no_exchange_ab and args.variant == "merged":
         exchange_ab = {}
         k_ab = max(10, min(args.steps, 40))
-        extras["exchange_ab"] = exchange_ab   # (filled leg by leg: the watchdog reports the legs that finished)
+        extras["exchange_ab"] = {}            # (published leg by leg: the watchdog reports the legs that finished)
         # (the default's legs first; the last two need stream wait-value support)
         for mode, name in ((0, "unsplit"), (2, "automatic"), (2, "automatic_one_combine_launch"), (1, "boundary_first")):
             extras["stage"] = f"exchange A/B leg '{name}'"
             try:
-                if name == "automatic_one_combine_launch":
-                    os.environ["BP5_COMBINE_SIGNAL"] = "1"    # read by the library per operator application (every rank sets it here, in step)
-                else:
-                    os.environ.pop("BP5_COMBINE_SIGNAL", None)
+                op.mf_data.set_tuning("combine_signal", 1 if name == "automatic_one_combine_launch" else 0)   # (every rank, in step)
                 op.mf_data.set_overlap(mode)
                 timed_solve(3)
                 actl, adt = timed_solve(k_ab, profile=False)
@@ -517,20 +532,22 @@ def main():
                     entry["phases_ms_max_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "max")
                     entry["phases_ms_min_over_ranks"][ph] = reduce_ranks(pctl.phase_ms[i], "min")
                 exchange_ab[name] = entry
+                extras["exchange_ab"] = dict(exchange_ab)
             except Exception as e:   # noqa: BLE001
                 # a diagnostic leg: report, skip the remaining legs (the other ranks may be inside a collective of this one: the watchdog ends that)
                 sys.stderr.write(f"[bench rank {rank}/{world}] exchange A/B leg '{name}' (bp5_mf_set_overlap({mode})) failed: {type(e).__name__}: {e}\n")
                 exchange_ab[name] = {"error": f"{type(e).__name__}: {e}"}
                 break
-        os.environ.pop("BP5_COMBINE_SIGNAL", None)
+        op.mf_data.set_tuning("combine_signal", 0)
         op.mf_data.set_overlap(args.overlap)
         exchange_ab["note"] = ("same problem, same kernels, same bits; unsplit = gather, one launch, combine, scatter-add on the compute stream; "
                                "boundary_first = ghost-touching bricks first inside the launch, ghost rows + scatter-add on the communication stream "
                                "under the interior bricks; automatic = the library's default: one launch, ghost rows combined first, scatter-add on "
                                "the communication stream under the owned-row combine; automatic_one_combine_launch = the same with ghost rows and owned rows in ONE "
-                               "combine launch, the exchange released by a stream wait-value (BP5_COMBINE_SIGNAL=1: slower on one GPU, profiles/r3 z_*).  phases: HIP "
+                               "combine launch, the exchange released by a stream wait-value (BP5_TUNE_COMBINE_SIGNAL: slower on one GPU, profiles/r3 z_*).  phases: HIP "
                                "events on the solver's stream (exchange = exposed part incl. unpack; gather_wait = exposed part of the ghost "
                                "gather that travels under the vector update)")
+        extras["exchange_ab"] = dict(exchange_ab)
 
     # achievable-stream figure: device copy y = 1.0 * x over the solver's vectors, read 8 + write 8 B per entry
     extras["stage"] = "copy-stream measurement"
@@ -552,31 +569,47 @@ def main():
     extras["stream_copy_gbs"] = stream_copy_gbs
 
     # BASELINE config 4 as one line: the other degrees at their ~5e7-DoF sizes, one short solve each (N = 1)
+    # Both quadratures per degree (the reference's COLLOCATION switch, bp5/step-64.cu:48,243-247): Gauss(p+1) is the
+    # reference default and the line's `value`; GLL(p+1) -- true BP5: collocated, one third of the contractions on the same bytes -- is
+    # reported beside it per degree ("gll").
     sweep = None
     if args.config == 4 and world == 1:
         sweep = []
-        extras["sweep"] = sweep
         extras["stage"] = "config-4 degree sweep"
-        for q in range(1, 9):
-            if q == p and not args.cells:
-                r_q = mesh.n_cells * (q + 1) ** 3 / mesh.n_owned
-                sweep.append({"degree": q, "cells": list(cells), "dofs": n_global, "value": value, "ms_per_step": dt / max(iters, 1) * 1e3,
-                              "kernel": ctl.apply_kernel, "frac_of_hbm_peak": value * algorithmic_bytes_per_dof(q, mesh.n_cells, mesh.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
-                continue
-            nq = CONFIG_SIZES[q]
-            mq, _, _ = build(q, (nq, nq, nq))
-            oq = pkg.HelmholtzOperator(mq, quad, km, device=local_rank) if args.operator == "helmholtz" else \
-                pkg.PoissonOperator(mq, quad, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
+        other_quad = pkg.QUAD_GLL if quad == pkg.QUAD_GAUSS else pkg.QUAD_GAUSS
+        quad_name = {pkg.QUAD_GAUSS: "gauss", pkg.QUAD_GLL: "gll"}
+
+        def one(q, mq, qd):
+            oq = pkg.HelmholtzOperator(mq, qd, km, device=local_rank) if args.operator == "helmholtz" else \
+                pkg.PoissonOperator(mq, qd, km, device=local_rank, geometry=pkg.GEOM_MERGED6 if G == 6 else pkg.GEOM_AFFINE)
             bq, xq = oq.assemble_rhs(), oq.initialize_dof_vector()
             timed_solve(3, oq, xq, bq)
             cq, dq = timed_solve(max(10, min(args.steps, 30)), oq, xq, bq)
             vq = int(mq.n_global_dofs) * cq.last_step() / dq
-            sweep.append({"degree": q, "cells": [nq, nq, nq], "dofs": int(mq.n_global_dofs), "value": vq, "ms_per_step": dq / max(cq.last_step(), 1) * 1e3,
-                          "kernel": cq.apply_kernel, "dot_products_fused": bool(cq.dot_products_fused),
-                          "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS})
+            e = {"value": vq, "ms_per_step": dq / max(cq.last_step(), 1) * 1e3, "kernel": cq.apply_kernel, "dot_products_fused": bool(cq.dot_products_fused),
+                 "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS}
             oq.mf_data.close()
-            del oq, bq, xq, mq
+            del oq, bq, xq
             torch.cuda.empty_cache()
+            return e
+        for q in range(1, 9):
+            extras["stage"] = f"config-4 degree sweep, p = {q}"
+            if q == p and not args.cells:
+                nq, mq = cells[0], mesh
+                e = {"value": value, "ms_per_step": dt / max(iters, 1) * 1e3, "kernel": ctl.apply_kernel, "dot_products_fused": bool(ctl.dot_products_fused),
+                     "frac_of_hbm_peak": value * algorithmic_bytes_per_dof(q, mesh.n_cells, mesh.n_owned, G=G) / 1e9 / HBM_PEAK_GBS}
+            else:
+                nq = CONFIG_SIZES[q]
+                mq, _, _ = build(q, (nq, nq, nq))
+                e = one(q, mq, quad)
+            entry = {"degree": q, "cells": [nq, nq, nq], "dofs": int(mq.n_global_dofs), "quadrature": quad_name[quad]}
+            entry.update(e)
+            if not args.no_sweep_other_quadrature:
+                entry[quad_name[other_quad]] = one(q, mq, other_quad)
+            sweep.append(entry)
+            extras["sweep"] = list(sweep)
+            if mq is not mesh:
+                del mq
 
     if rank == 0:
         extras["stage"] = "HBM traffic passes (rocprofv3 --pmc children)"

@@ -133,6 +133,9 @@ def lib():
         "bp5_mf_get_apply_variant": (i32, [vp, C.POINTER(C.c_int)]),
         "bp5_mf_set_block_workgroups": (i32, [vp, i32]),
         "bp5_mf_set_streaming": (i32, [vp, i32]),
+        "bp5_mf_set_tuning": (i32, [vp, i32, i32]),
+        "bp5_mf_get_tuning": (i32, [vp, i32, C.POINTER(C.c_int)]),
+        "bp5_mf_wait_value_available": (i32, [vp, C.POINTER(C.c_int)]),
         "bp5_mf_block_plan_info": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
         "bp5_assemble_rhs": (i32, [vp, vp]),
         "bp5_compute_diagonal": (i32, [vp, vp, vp, i32]),

@@ -26,6 +26,7 @@ extern "C" int bp5_copy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(
 extern "C" int bp5_copy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return BP5_OK; }
 
 // ------------------------------------------------------------------------------------ create / destroy
+static void tuning_from_environment(bp5_mf *mf);
 static void pack_tab(const Tables &t, std::vector<double> &v)
 {
   const int n = t.n;
@@ -59,6 +60,7 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
   mf->n_cells = d->n_cells; mf->n_interior = d->n_interior_cells; mf->n_owned = d->n_owned; mf->n_ghost = d->n_ghost;
   mf->n_constrained = d->n_constrained;
   mf->tab = tab; mf->tab_gauss = tabg;
+  tuning_from_environment(mf);
   { // metric layout (A/B knob: BP5_COEF_LAYOUT = plane | cell)
     const char *e = getenv("BP5_COEF_LAYOUT");
     const bool cell_major = e && !strcmp(e, "cell");
@@ -205,6 +207,7 @@ extern "C" int bp5_mf_coef_size(const bp5_mf *mf, size_t *n)
 {
   if (!mf || !n) return fail(BP5_ERR_INVALID, "null argument");
   *n = (size_t)mf->n_planes() * mf->n_cells * mf->n3;
+  mf->coef_planes_committed = mf->n_planes();
   return BP5_OK;
 }
 extern "C" int bp5_mf_set_operator(bp5_mf *mf, int op)
@@ -213,6 +216,8 @@ extern "C" int bp5_mf_set_operator(bp5_mf *mf, int op)
   if (op == BP5_OP_HELMHOLTZ && (mf->has_hanging || mf->geometry_mode == BP5_GEOM_AFFINE))
     return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs a conforming mesh and the six-plane geometry (hanging nodes: the facade's FEEvaluation)");
   if (op == BP5_OP_HELMHOLTZ && mf->apply_variant != 0 && mf->apply_variant != 56) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator runs apply variants 0 and 56");
+  if (mf->coef_planes_committed && mf->coef_planes_committed != (op == BP5_OP_HELMHOLTZ ? 7 : 6))
+    return fail(BP5_ERR_INVALID, "the metric array of this handle has been sized or filled for another plane count: set the operator before bp5_mf_coef_size / bp5_mf_compute_merged_metric");
   mf->operator_kind = op;
   mf->auto_block = -1; // (decided per operator: the Helmholtz build of the block kernel runs two workgroups per CU)
   return BP5_OK;
@@ -240,6 +245,7 @@ extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
   if (!mf) return fail(BP5_ERR_INVALID, "null handle");
   if (mf->has_hanging) { // 0: the library decides; 56: block kernel (deterministic; needs cell blocks); 90: pencil kernel with atomics (any mesh)
     if (v != 0 && v != 90 && !(v == 56 && block_lpc(mf->degree) != 0)) return fail(BP5_ERR_UNSUPPORTED, "meshes with hanging nodes run apply variants 90 (pencil kernel) and 56 (block kernel)");
+    if (v == 56 && mf->geometry_mode == BP5_GEOM_AFFINE) return fail(BP5_ERR_UNSUPPORTED, "hanging nodes in the affine geometry mode run the pencil kernel: apply variants 0 and 90");
     mf->apply_variant = v;
     return BP5_OK;
   }
@@ -331,6 +337,7 @@ extern "C" int bp5_mf_set_geometry_mode(bp5_mf *mf, int mode)
   if (mode != BP5_GEOM_MERGED6 && mode != BP5_GEOM_AFFINE) return fail(BP5_ERR_INVALID, "unknown geometry mode");
   HIP_TRY(hipSetDevice(mf->device));
   if (mode == BP5_GEOM_AFFINE && mf->operator_kind == BP5_OP_HELMHOLTZ) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs the six-plane geometry");
+  if (mode == BP5_GEOM_AFFINE && mf->has_hanging && mf->apply_variant == 56) return fail(BP5_ERR_UNSUPPORTED, "hanging nodes in the affine geometry mode run the pencil kernel: set apply variant 0 or 90 first");
   if (mode == BP5_GEOM_AFFINE && !mf->d_scalar_plane) {
     double *sp = nullptr, *gc = nullptr, *dev = nullptr;
     const size_t nq = (size_t)mf->n_cells * mf->n3;
@@ -365,6 +372,7 @@ extern "C" int bp5_mf_compute_merged_metric(bp5_mf *mf, double *coef)
   o.coef = coef;
   o.plane_stride = mf->coef_plane_stride; o.cell_stride = mf->coef_cell_stride;
   o.helmholtz = mf->operator_kind == BP5_OP_HELMHOLTZ;
+  mf->coef_planes_committed = mf->n_planes();
   if (o.helmholtz && mf->coef_cell_stride != (uint64_t)mf->n3) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator needs the plane-major metric layout");
   DISPATCH_N(launch_geometry, mf, o);
 }
@@ -633,7 +641,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
         std::vector<uint32_t> lat;
         std::vector<uint16_t> cpos;
         dp.n_lattice_blocks = detect_lattice_blocks(mf->h_l2g.data(), n, h.group_cell_off, h.off, h.dofs, lat, cpos);
-        const bool lattice_enabled = [] { const char *e = getenv("BP5_LATTICE_INDICES"); return !(e && e[0] == '0'); }(); // A/B knob for tools and tests (read when the plan is built)
+        const bool lattice_enabled = mf->tune[BP5_TUNE_LATTICE_INDICES] != 0; // (A/B knob, fixed once the plan is built)
         if (dp.n_lattice_blocks && lattice_enabled) {
           BP5_TRY(upload(&dp.lattice, lat.data(), lat.size()));
           BP5_TRY(upload(&dp.cell_pos, cpos.data(), cpos.size()));
@@ -810,8 +818,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
       bp5_mf::DevPlan *dp = nullptr;
       mf->auto_block = 0;
       if (get_plan_raw(mf, -block_cpt(mf), &dp, 64) == BP5_OK && dp->packed) {
-        const int n = mf->degree + 1;
-        const size_t lds = ((size_t)block_cpt(mf) * (n * (n * n + 1) + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
+        const size_t lds = block_default_lds_bytes(mf->degree, dp->max_list); // (the launcher's own formula)
         if (!mf->n_cus) {
           hipDeviceProp_t prop;
           if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
@@ -841,9 +848,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
     if (get_plan_raw(mf, -block_cpt(mf), &dp, 64) == BP5_OK) {
       // LDS of the default shape: one transpose tile per cell slot + the brick's accumulator + two run tables; p <= 4 must fit
       // three workgroups per CU, p >= 5 (more registers per lane: two workgroups per CU anyway) two
-      const int n = mf->degree + 1, ps = mf->degree == 4 ? LdsLayout<5, 32>::PS : mf->degree == 6 ? LdsLayout<7, 64>::PS : mf->degree == 5 ? LdsLayout<6, 64>::PS :
-                                         mf->degree == 7 ? LdsLayout<8, 64>::PS : mf->degree == 8 ? LdsLayout<9, 128>::PS : mf->degree == 3 ? LdsLayout<4, 16>::PS : mf->degree == 1 ? LdsLayout<2, 4>::PS : LdsLayout<3, 16>::PS;
-      const size_t lds = ((size_t)block_cpt(mf) * (n * ps + 3) + dp->max_list) * sizeof(double) + 4 * BLOCK_MAX_RUNS * sizeof(uint32_t);
+      const size_t lds = block_default_lds_bytes(mf->degree, dp->max_list); // (the launcher's own formula)
       mf->auto_block = lds * (mf->degree <= 4 ? 3 : 2) <= 160 * 1024 && (mf->degree == 4 || dp->packed);
       // persistent workgroups need enough bricks each to balance: round 1 measured 3.6 bricks per workgroup (54^3 cells)
       // 4 % behind the pencil kernel as a bare operator; with the CG dot products fused into the write-out the block kernel
@@ -1020,13 +1025,21 @@ static inline int stream_grid(size_t n, int per_thread)
   size_t b = (n + (size_t)VB * per_thread - 1) / ((size_t)VB * per_thread);
   return (int)std::min<size_t>(std::max<size_t>(b, 1), MAXBLK);
 }
+// Streaming kernels WITHOUT a reduction: one trip per workgroup ("flat" launch).  profiles/r4 hbm_sweep: on a capped grid-stride grid the
+// workgroups drift apart and the write stream loses its locality -- fill 4.3 against 6.7 TB/s, the update kernels 4.8-4.9 against 5.6-5.9
+static inline int stream_grid_flat(const bp5_mf *mf, size_t n, int per_thread)
+{
+  if (!mf->tune[BP5_TUNE_UPDATE_FLAT]) return stream_grid(n, per_thread);
+  const size_t b = (n + (size_t)VB * per_thread - 1) / ((size_t)VB * per_thread);
+  return (int)std::min<size_t>(std::max<size_t>(b, 1), (size_t)1 << 30);
+}
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 extern "C" int bp5_vec_fill(bp5_mf *mf, double *v, double value, size_t n)
 {
   if (!mf || !v) return fail(BP5_ERR_INVALID, "null argument");
   if (!aligned16(v)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
-  hipLaunchKernelGGL(vec_kernel<0>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, v, (const double *)nullptr, value, 0.0, n);
+  hipLaunchKernelGGL(vec_kernel<0>, dim3(stream_grid_flat(mf, n, 2)), dim3(VB), 0, mf->stream, v, (const double *)nullptr, value, 0.0, n);
   KERNEL_CHECK();
   return BP5_OK;
 }
@@ -1034,7 +1047,7 @@ extern "C" int bp5_vec_axpy(bp5_mf *mf, double *y, double a, const double *x, si
 {
   if (!mf || !y || !x) return fail(BP5_ERR_INVALID, "null argument");
   if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
-  hipLaunchKernelGGL(vec_kernel<1>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, y, x, 0.0, a, n);
+  hipLaunchKernelGGL(vec_kernel<1>, dim3(stream_grid_flat(mf, n, 2)), dim3(VB), 0, mf->stream, y, x, 0.0, a, n);
   KERNEL_CHECK();
   return BP5_OK;
 }
@@ -1042,7 +1055,7 @@ extern "C" int bp5_vec_equ(bp5_mf *mf, double *y, double a, const double *x, siz
 {
   if (!mf || !y || !x) return fail(BP5_ERR_INVALID, "null argument");
   if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
-  hipLaunchKernelGGL(vec_kernel<2>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, y, x, 0.0, a, n);
+  hipLaunchKernelGGL(vec_kernel<2>, dim3(stream_grid_flat(mf, n, 2)), dim3(VB), 0, mf->stream, y, x, 0.0, a, n);
   KERNEL_CHECK();
   return BP5_OK;
 }
@@ -1050,7 +1063,7 @@ extern "C" int bp5_vec_sadd(bp5_mf *mf, double *y, double s, double a, const dou
 {
   if (!mf || !y || !x) return fail(BP5_ERR_INVALID, "null argument");
   if (!aligned16(y) || !aligned16(x)) return fail(BP5_ERR_INVALID, "vectors must be 16-byte aligned");
-  hipLaunchKernelGGL(vec_kernel<3>, dim3(stream_grid(n, 2)), dim3(VB), 0, mf->stream, y, x, s, a, n);
+  hipLaunchKernelGGL(vec_kernel<3>, dim3(stream_grid_flat(mf, n, 2)), dim3(VB), 0, mf->stream, y, x, s, a, n);
   KERNEL_CHECK();
   return BP5_OK;
 }
@@ -1160,19 +1173,87 @@ static int halo_streams(bp5_mf *mf)
   HIP_TRY(hipStreamCreateWithPriority(&mf->comm_stream, hipStreamNonBlocking, prio_hi));
   for (hipEvent_t &e : mf->ev_halo) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // boundary-first schedule inside ONE launch: the communication stream waits for a counter the block kernel's workgroups bump once
-  // their ghost-touching bricks are written out (hipStreamWaitValue64: a barrier-value packet, no kernel, ~1 us wake-up: profiles/r3).
-  // Without it (or with BP5_BOUNDARY_FIRST=launches, the A/B knob) the ghost-touching bricks get a launch of their own.
+  // their ghost-touching bricks are written out (hipStreamWaitValue64).  The counter is plain device memory: there the runtime implements
+  // the wait by POLLING (profiles/r3/a_wait_value_probe.txt: same timing as a spin kernel; on signal memory the wait released only after
+  // the producer kernel had ended), i.e. a mid-kernel release rests on runtime behaviour the API does not promise.  So the capability bit
+  // alone is not trusted: a one-off producer / consumer pair checks that the waiting stream really is released while the producing kernel
+  // is still running (bounded: the producer gives up after 2 ms); if not, the ghost-touching bricks get a launch of their own
+  // (BP5_TUNE_BOUNDARY_FIRST = 0 selects that form by hand).
   int can = 0;
   if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, mf->device) != hipSuccess) can = 0;
-  const char *e = getenv("BP5_BOUNDARY_FIRST");
-  if (e && !strcmp(e, "launches")) can = 0;
-  mf->can_wait_value = can;
   if (can && !mf->d_signal) {
-    HIP_TRY(hipMalloc((void **)&mf->d_signal, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(mf->d_signal, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&mf->d_signal, 4 * sizeof(unsigned long long))); // [0] the counter, [1] consumer-ran flag, [2] self-check result
+    HIP_TRY(hipMemset(mf->d_signal, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipStreamSynchronize(nullptr));
     mf->signal_target = 0;
   }
+  if (can) {
+    mf->signal_target += 1;
+    hipLaunchKernelGGL(wait_value_probe_producer, dim3(1), dim3(64), 0, mf->stream, mf->d_signal, mf->d_signal + 1, mf->d_signal + 2, 200000LL /* 2 ms of the 100 MHz clock */);
+    KERNEL_CHECK();
+    const bool waited = hipStreamWaitValue64(mf->comm_stream, mf->d_signal, mf->signal_target, hipStreamWaitValueGte, ~0ull) == hipSuccess;
+    if (waited) { hipLaunchKernelGGL(wait_value_probe_consumer, dim3(1), dim3(64), 0, mf->comm_stream, mf->d_signal + 1); KERNEL_CHECK(); }
+    else (void)hipGetLastError();
+    HIP_TRY(hipStreamSynchronize(mf->stream));
+    HIP_TRY(hipStreamSynchronize(mf->comm_stream));
+    unsigned long long released_mid_kernel = 0;
+    HIP_TRY(hipMemcpy(&released_mid_kernel, mf->d_signal + 2, sizeof(released_mid_kernel), hipMemcpyDeviceToHost));
+    if (!waited || !released_mid_kernel) can = 0;
+  }
+  mf->wait_value_ok = can;
+  mf->can_wait_value = can && mf->tune[BP5_TUNE_BOUNDARY_FIRST] != 0;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_wait_value_available(bp5_mf *mf, int *available)
+{
+  if (!mf || !available) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  BP5_TRY(halo_streams(mf));
+  *available = mf->wait_value_ok == 1;
+  return BP5_OK;
+}
+static int env_int(const char *name, int fallback)
+{
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : fallback;
+}
+// initial values of the handle's knobs: the environment is read here, once per handle, and nowhere else (bp5.h: BP5_TUNE_*)
+static void tuning_from_environment(bp5_mf *mf)
+{
+  mf->tune[BP5_TUNE_LATTICE_INDICES] = env_int("BP5_LATTICE_INDICES", 1) != 0;
+  mf->tune[BP5_TUNE_EARLY_GATHER] = env_int("BP5_EARLY_GATHER", 1) != 0;
+  mf->tune[BP5_TUNE_COMBINE_SIGNAL] = env_int("BP5_COMBINE_SIGNAL", 0) == 1;
+  { const char *e = getenv("BP5_BOUNDARY_FIRST"); mf->tune[BP5_TUNE_BOUNDARY_FIRST] = !(e && !strcmp(e, "launches")); }
+  mf->tune[BP5_TUNE_FOLD_SMALL] = env_int("BP5_FOLD_SMALL", 1) != 0;
+  { const int u = env_int("BP5_UPDATE_UNROLL", 1); mf->tune[BP5_TUNE_UPDATE_UNROLL] = (u == 2 || u == 4) ? u : 1; }
+  mf->tune[BP5_TUNE_UPDATE_FLAT] = env_int("BP5_UPDATE_FLAT", 1) != 0;
+  { const int v = env_int("BP5_UPDATE_NT", -1); mf->tune[BP5_TUNE_UPDATE_NT] = v < 0 ? -1 : v != 0; }
+}
+extern "C" int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value)
+{
+  if (!mf || knob < 0 || knob >= BP5_TUNE_COUNT) return fail(BP5_ERR_INVALID, "unknown tuning knob");
+  switch (knob) {
+    case BP5_TUNE_UPDATE_UNROLL:
+      if (value != 1 && value != 2 && value != 4) return fail(BP5_ERR_INVALID, "BP5_TUNE_UPDATE_UNROLL: 1, 2 or 4");
+      break;
+    case BP5_TUNE_UPDATE_NT:
+      if (value < -1 || value > 1) return fail(BP5_ERR_INVALID, "BP5_TUNE_UPDATE_NT: -1, 0 or 1");
+      break;
+    case BP5_TUNE_LATTICE_INDICES:
+      if (value != 0 && value != 1) return fail(BP5_ERR_INVALID, "switch: 0 or 1");
+      if (value != mf->tune[knob] && mf->plans.count(-block_cpt(mf))) return fail(BP5_ERR_INVALID, "BP5_TUNE_LATTICE_INDICES: the block plan of this handle is already built");
+      break;
+    default:
+      if (value != 0 && value != 1) return fail(BP5_ERR_INVALID, "switch: 0 or 1");
+  }
+  mf->tune[knob] = value;
+  if (knob == BP5_TUNE_BOUNDARY_FIRST && mf->wait_value_ok >= 0) mf->can_wait_value = mf->wait_value_ok == 1 && value != 0;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_get_tuning(const bp5_mf *mf, int knob, int *value)
+{
+  if (!mf || !value || knob < 0 || knob >= BP5_TUNE_COUNT) return fail(BP5_ERR_INVALID, "unknown tuning knob");
+  *value = mf->tune[knob];
   return BP5_OK;
 }
 extern "C" int bp5_mf_set_overlap(bp5_mf *mf, int mode)
@@ -1508,13 +1589,13 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
       if (st == BP5_OK) st = launch_apply(mf, coef, src, dst, 0, mf->n_cells, true);
       mf->defer_combine = false;
       if (st == BP5_OK) st = prof.mark(2);
-      // BP5_COMBINE_SIGNAL=1 (A/B knob for tools and tests, read per application): the two combine launches as ONE -- its first workgroups
+      // BP5_TUNE_COMBINE_SIGNAL (A/B knob of the handle): the two combine launches as ONE -- its first workgroups
       // complete the ghost rows and count themselves in, the communication stream waits for the count (stream wait-value) and starts the
       // exchange while the same launch walks the owned rows; same tiles and columns as the two launches: same bits.  One launch, one gap and
       // one cross-stream event less -- and on ONE GPU 16 us per iteration SLOWER than the two launches (0.547 against 0.531 ms on the slab of
       // rank 3 of 8, profiles/r3 z_*: the RCCL kernel then runs beside the bandwidth-bound combine pass from its first microsecond and both
       // crawl), hence not the default; whether a longer xGMI transfer pays for the earlier start is for a multi-GPU run to say
-      const bool combine_signal = [] { const char *e = getenv("BP5_COMBINE_SIGNAL"); return e && e[0] == '1'; }();
+      const bool combine_signal = mf->tune[BP5_TUNE_COMBINE_SIGNAL] != 0;
       const bool one_combine = combine_signal && mf->can_wait_value == 1 && mf->n_ghost && mf->d_signal && dp && dp->n_shared > dp->n_shared_owned && dp->cr_tile && !mf->combine_csr; // (ghost rows among the shared ones: at least one workgroup signals)
       if (one_combine) {
         if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST_THEN_OWNED);
@@ -1732,7 +1813,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   // one rank, separate dot-product kernel: the two small launches around an operator that scatters with atomics fold into their
   // neighbours -- the update kernel stores the zeros the operator needs in h / v (it holds the values in registers for the last time),
   // the dot-product kernel applies the Dirichlet copy while it reads both vectors (bitmap of the Dirichlet DoFs)
-  static const bool fold_enabled = [] { const char *e = getenv("BP5_FOLD_SMALL"); return !(e && e[0] == '0'); }(); // A/B knob for tools
+  const bool fold_enabled = mf->tune[BP5_TUNE_FOLD_SMALL] != 0; // A/B knob of the handle
   const bool fold_small = fold_enabled && !fused_dots && !user && !dist_solve;
   const bool prezero = fold_small && mf->n_ghost == 0 && !variant_overwrites(mf, effective_variant(mf, 0, mf->n_cells)); // (the update kernels cover owned entries)
   struct FoldGuard { bp5_mf *m; ~FoldGuard() { m->solver_prezeroed = m->solver_copies_dirichlet = false; } } fold_guard{mf};
@@ -1771,7 +1852,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
       KERNEL_CHECK();
       BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
       hipLaunchKernelGGL(cg_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
-      hipLaunchKernelGGL(cg_direction_kernel, dim3(grid2), dim3(VB), 0, s, d, g, diag, n, mf->d_sc, mf->d_st);
+      hipLaunchKernelGGL(cg_direction_kernel, dim3(stream_grid_flat(mf, n, 2)), dim3(VB), 0, s, d, g, diag, n, mf->d_sc, mf->d_st);
       KERNEL_CHECK();
       if (check > 0 && it % check == 0 && it < prm->max_iter) {
         BP5_TRY(poll_state(mf));
@@ -1787,33 +1868,28 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
     BP5_TRY(bp5_comm_allreduce_sum(mf, mf->d_sc + SC_GG, 2));
     hipLaunchKernelGGL(cgm_init_control_kernel, dim3(1), dim3(1), 0, s, mf->d_sc, mf->d_st);
     KERNEL_CHECK();
-    // update kernels: U chunks of 256 pairs per loop trip, all loads of a trip ahead of its stores (A/B knob for tools:
-    // BP5_UPDATE_UNROLL = 1 | 2 | 4; profiles/r2: 1.03 / 1.00 / 0.99 ms per iteration at 1e8 DoFs; default 4)
-    static const int unroll = [] { const char *e = getenv("BP5_UPDATE_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 1 || u == 2) ? u : 4; }();
-    const int gridu = stream_grid(n, 2 * unroll);
-    const bool streaming = streaming_accesses(mf);
+    // update kernels: U chunks of 256 pairs per workgroup (flat launch: one trip per workgroup), all loads ahead of the first store.
+    // profiles/r4 hbm_sweep: U = 1 flat 5.5-5.9 TB/s, the capped grid-stride grid of rounds 1-3 (U = 4, 2048 workgroups) 4.8-4.9
+    const int unroll = mf->tune[BP5_TUNE_UPDATE_UNROLL];
+    const int gridu = stream_grid_flat(mf, n, 2 * unroll);
+    // v and x non-temporally: at every size since round 4 (-1 = on; profiles/r4 ab_update_*: 3.741 -> 3.707 ms per iteration at 1e8 DoFs with the flat
+    // launch, 0.4075 -> 0.4025 at 1e7; rounds 1-3 followed the streaming policy of the metric loads, which is off at 1e8 DoFs)
+    const bool streaming = mf->tune[BP5_TUNE_UPDATE_NT] != 0;
     auto launch_update = [&](int mode) {
-      if (prezero && mode != 0) {
-        if (mode == 1) hipLaunchKernelGGL((cgm_update_kernel<1, 4, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-        else hipLaunchKernelGGL((cgm_update_kernel<2, 4, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-        return;
-      }
-#define BP5_UPD(M, U) hipLaunchKernelGGL((cgm_update_kernel<M, U>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st)
-      if (streaming && unroll == 4 && mode != 0) { // (profiles/r3/README.md, x_*: -2 ... -3 % per iteration up to 2e7 DoFs, +1 % at 1e8)
-        if (mode == 1) hipLaunchKernelGGL((cgm_update_kernel<1, 4, false, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-        else hipLaunchKernelGGL((cgm_update_kernel<2, 4, false, true>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st);
-        return;
-      }
-      if (unroll == 1) { if (mode == 0) BP5_UPD(0, 1); else if (mode == 1) BP5_UPD(1, 1); else BP5_UPD(2, 1); }
-      else if (unroll == 4) { if (mode == 0) BP5_UPD(0, 4); else if (mode == 1) BP5_UPD(1, 4); else BP5_UPD(2, 4); }
-      else { if (mode == 0) BP5_UPD(0, 2); else if (mode == 1) BP5_UPD(1, 2); else BP5_UPD(2, 2); }
+#define BP5_UPD(M, U, ZV, NT) hipLaunchKernelGGL((cgm_update_kernel<M, U, ZV, NT>), dim3(gridu), dim3(VB), 0, s, d, g, h, x, diag, n, mf->d_sc, mf->d_st)
+#define BP5_UPD_U(M, ZV, NT) do { if (unroll == 1) BP5_UPD(M, 1, ZV, NT); else if (unroll == 2) BP5_UPD(M, 2, ZV, NT); else BP5_UPD(M, 4, ZV, NT); } while (0)
+      if (mode == 0) { BP5_UPD_U(0, false, false); return; }
+      if (prezero) { if (mode == 1) BP5_UPD_U(1, true, false); else BP5_UPD_U(2, true, false); return; }
+      if (streaming) { if (mode == 1) BP5_UPD_U(1, false, true); else BP5_UPD_U(2, false, true); return; }
+      if (mode == 1) BP5_UPD_U(1, false, false); else BP5_UPD_U(2, false, false);
+#undef BP5_UPD_U
 #undef BP5_UPD
     };
     const bool fused = fused_dots;
     // fused iteration across ranks: the values of the NEW p at the DoFs this rank sends are computed into the send buffer first, so the
     // ghost gather of p runs on the communication stream underneath the update kernel (which touches owned entries only); the operator
     // then just waits for the event
-    const bool early_gather_enabled = [] { const char *e = getenv("BP5_EARLY_GATHER"); return !(e && e[0] == '0'); }(); // A/B knob for tools and tests (read per solve)
+    const bool early_gather_enabled = mf->tune[BP5_TUNE_EARLY_GATHER] != 0; // A/B knob of the handle
     const bool early_gather = fused && dist_solve && early_gather_enabled;
     auto gather_under_update = [&](int mode) -> int {
       BP5_TRY(halo_streams(mf));

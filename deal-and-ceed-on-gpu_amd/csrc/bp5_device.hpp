@@ -52,6 +52,7 @@ struct bp5_mf {
   uint32_t n_cells = 0, n_interior = 0, n_owned = 0, n_ghost = 0, n_constrained = 0;
   int apply_variant = 0, n_cus = 0, geometry_mode = 0, march_max_steps = 32;
   int operator_kind = 0; // BP5_OP_POISSON | BP5_OP_HELMHOLTZ (seven planes: six merged + the mass plane a JxW)
+  mutable int coef_planes_committed = 0; // planes of the metric array the caller has sized (bp5_mf_coef_size) or filled: set_operator may not change the count afterwards
   int n_planes() const { return operator_kind == BP5_OP_HELMHOLTZ ? 7 : 6; }
   uint32_t blk_b0 = 0, blk_b1 = 0; // block range of the next block-kernel launch (0,0 = all blocks)
   bool combine_csr = false; // A/B: per-DoF CSR combine kernel instead of the run-length one
@@ -101,7 +102,10 @@ struct bp5_mf {
   bool blk_two_parts = false, blk_signal = false;
   unsigned long long *d_signal = nullptr;
   uint64_t signal_target = 0;
-  int can_wait_value = -1;    // hipDeviceAttributeCanUseStreamWaitValue (and not switched off by BP5_BOUNDARY_FIRST=launches)
+  int wait_value_ok = -1;     // -1 not probed; 1: hipDeviceAttributeCanUseStreamWaitValue AND the producer / consumer self-check saw a mid-kernel release
+  int can_wait_value = -1;    // wait_value_ok and not switched off by BP5_TUNE_BOUNDARY_FIRST = 0
+  // per-handle tuning / A-B knobs (bp5.h: BP5_TUNE_*): initial values from the environment, read once by bp5_mf_create
+  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1};
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
@@ -256,6 +260,33 @@ inline int launch_apply_t(bp5_mf *mf, const double *coef, const double *src, dou
   return BP5_OK;
 }
 
+// LDS bytes of one block-kernel workgroup: transpose tiles of the cell slots (two per slot where the cells span waves: BlockPass::PP),
+// the brick's accumulator (and its staged src: ABL & 524288), two run tables and two lattice tables.  The ONE formula: the launcher
+// sizes the launch with it and the library's automatic kernel choice (effective_variant) counts workgroups per CU with it.
+template <int P, bool COLL, int LPC, int ABL>
+constexpr size_t block_lds_bytes(uint32_t max_list)
+{
+  return ((size_t)(256 / LPC) * (size_t)BlockPass<P, COLL, LPC, SC_OWNER_SET, ABL>::TILE_CS + ((ABL & 524288) ? 2 : 1) * (size_t)max_list) * sizeof(double) +
+         ((ABL & 16384) ? (4 * BLOCK_MAX_RUNS + 2 * BLOCK_LATTICE_WORDS) * sizeof(uint32_t) : 0);
+}
+// ... of the default shape of a degree (sequential tiles, metric loaded in its own pass, run-length write-out, packed indices; the
+// Helmholtz, hanging-node, fused-CG and lattice builds have the same tiles)
+inline size_t block_default_lds_bytes(int degree, uint32_t max_list)
+{
+  constexpr int D = 2048 + 8192 + 16384 + 262144;
+  switch (degree) {
+    case 1: return block_lds_bytes<1, false, block_lpc(1), D>(max_list);
+    case 2: return block_lds_bytes<2, false, block_lpc(2), D>(max_list);
+    case 3: return block_lds_bytes<3, false, block_lpc(3), D>(max_list);
+    case 4: return block_lds_bytes<4, false, block_lpc(4), D>(max_list);
+    case 5: return block_lds_bytes<5, false, block_lpc(5), D>(max_list);
+    case 6: return block_lds_bytes<6, false, block_lpc(6), D>(max_list);
+    case 7: return block_lds_bytes<7, false, block_lpc(7), D>(max_list);
+    case 8: return block_lds_bytes<8, false, block_lpc(8), D>(max_list);
+  }
+  return ~(size_t)0;
+}
+
 // block-assembled kernel; falls back to the team kernel path when the range is partial
 template <int P, bool COLL, int LPC, int ABL = 0>
 inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, double *dst, bool overwrite)
@@ -264,9 +295,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
   constexpr int CPT = 256 / LPC;
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -CPT, &dp));
-  const size_t tile_cs = (size_t)BlockPass<P, COLL, LPC, SC_OWNER_SET, ABL>::TILE_CS; // (two tiles per cell slot where the cells span waves: BlockPass::PP)
-  const size_t lds = ((size_t)CPT * tile_cs + ((ABL & 524288) ? 2 : 1) * (size_t)dp->max_list) * sizeof(double) +
-                     ((ABL & 16384) ? (4 * BLOCK_MAX_RUNS + 2 * BLOCK_LATTICE_WORDS) * sizeof(uint32_t) : 0); // run tables + lattice tables (two blocks each)
+  const size_t lds = block_lds_bytes<P, COLL, LPC, ABL>(dp->max_list);
   if ((ABL & 16384) && dp->max_runs > (uint32_t)BLOCK_MAX_RUNS) return fail(BP5_ERR_UNSUPPORTED, "too many runs per block for the run-length write-out");
   if ((ABL & 262144) && !dp->packed) return fail(BP5_ERR_UNSUPPORTED, "more than 128 runs per block: packed indices unavailable");
   if ((ABL & 16777216) && !(dp->lattice && dp->n_lattice_blocks == dp->n_groups)) return fail(BP5_ERR_INVALID, "the lattice build needs a plan of lattice blocks only");

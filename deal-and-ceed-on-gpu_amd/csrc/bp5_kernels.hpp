@@ -3245,4 +3245,25 @@ static __global__ void cgm_init_control_kernel(double *sc, int *st)
   st[ST_DONE] = (sc[SC_RES] <= sc[SC_TOL]) ? 1 : 0;
 }
 
+// ---- self-check of the in-launch stream wait-value schedules (bp5_device.hip: halo_streams).  The producer counts itself in exactly like
+// apply_block_kernel's signal_part_done and then stays alive until the consumer -- enqueued on the waiting stream behind
+// hipStreamWaitValue64 -- has run, or 2 ms have passed: *result = 1 says the wait was released WHILE the producing kernel was running
+static __global__ void wait_value_probe_producer(unsigned long long *signal, unsigned long long *consumer_ran, unsigned long long *result, long long max_ticks)
+{
+  if (threadIdx.x != 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __hip_atomic_fetch_add(signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long ok = 0;
+  while ((long long)(wall_clock64() - t0) < max_ticks) { // bounded: the kernel ends whatever the runtime does
+    if (__hip_atomic_load(consumer_ran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(32);
+  }
+  __hip_atomic_store(result, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __global__ void wait_value_probe_consumer(unsigned long long *consumer_ran)
+{
+  if (threadIdx.x == 0) __hip_atomic_store(consumer_ran, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 } // namespace bp5

@@ -159,6 +159,24 @@ class MatrixFree:
         """1: non-temporal accesses to once-used data (metric planes; v, x in the update kernel), 0: ordinary, -1: by local size (default)."""
         _lib.check(_lib.lib().bp5_mf_set_streaming(self.handle, int(policy)))
 
+    TUNE = {"lattice_indices": 0, "early_gather": 1, "combine_signal": 2, "boundary_first": 3, "fold_small": 4, "update_unroll": 5,
+            "update_flat": 6, "update_nt": 7}   # bp5.h: BP5_TUNE_*
+
+    def set_tuning(self, knob, value):
+        """Per-handle A/B knob (bp5.h BP5_TUNE_*; same bits for every setting); knob by name or number."""
+        _lib.check(_lib.lib().bp5_mf_set_tuning(self.handle, int(self.TUNE.get(knob, knob)), int(value)))
+
+    def get_tuning(self, knob):
+        v = C.c_int()
+        _lib.check(_lib.lib().bp5_mf_get_tuning(self.handle, int(self.TUNE.get(knob, knob)), C.byref(v)))
+        return v.value
+
+    def wait_value_available(self):
+        """True when the in-launch stream wait-value schedules passed the handle's self-check (bp5.h)."""
+        v = C.c_int()
+        _lib.check(_lib.lib().bp5_mf_wait_value_available(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def block_plan_info(self):
         """(n_blocks, max_runs, packed_indices) of the block kernel's plan."""
         nb, mr, pk = C.c_uint32(), C.c_uint32(), C.c_int()

@@ -255,6 +255,37 @@ int bp5_mf_set_block_workgroups(bp5_mf *mf, int max_workgroups);
  * reused (p, r) from the 256 MB memory-side cache (-6 % per CG iteration at 1e7 DoFs, +1 % at 1e8), 0 = ordinary accesses,
  * -1 = chosen from the local size (default: non-temporal up to 2.4e7 local DoFs) */
 int bp5_mf_set_streaming(bp5_mf *mf, int policy);
+/* Per-handle tuning / A-B knobs (results are the same bits for every setting; two handles of one process may differ).  The
+ * environment variables named below are read ONCE, by bp5_mf_create, as the handle's initial values -- nothing on the apply or
+ * solve path reads the environment.
+ *   BP5_TUNE_LATTICE_INDICES   (env BP5_LATTICE_INDICES, default 1) closed-form indices for lattice blocks; 0 keeps the packed
+ *                              u16 stream.  Set before the block plan is built (first apply / solve / bp5_mf_block_plan_*).
+ *   BP5_TUNE_EARLY_GATHER      (env BP5_EARLY_GATHER, default 1) fused merged CG across ranks: the ghost gather of the new search
+ *                              direction travels under the update kernel (0: after it).
+ *   BP5_TUNE_COMBINE_SIGNAL    (env BP5_COMBINE_SIGNAL, default 0) default exchange schedule with ONE combine launch: the ghost rows
+ *                              first, the exchange released mid-launch by a stream wait-value (needs the capability below).
+ *   BP5_TUNE_BOUNDARY_FIRST    (env BP5_BOUNDARY_FIRST = signal | launches, default 1 = signal) boundary-first schedule inside one
+ *                              launch (stream wait-value) or as two launches (0).  The in-launch form is used only when the device
+ *                              reports hipDeviceAttributeCanUseStreamWaitValue AND a producer / consumer self-check, run once when the
+ *                              handle creates its communication stream, has seen the waiting stream released while the producing kernel
+ *                              was still running (on plain device memory the runtime implements the wait by polling; if that ever
+ *                              stops working mid-kernel the library falls back to two launches by itself).
+ *   BP5_TUNE_FOLD_SMALL        (env BP5_FOLD_SMALL, default 1) merged CG on the atomic kernels: zero-fill and Dirichlet copy folded
+ *                              into the neighbouring launches.
+ *   BP5_TUNE_UPDATE_UNROLL     (env BP5_UPDATE_UNROLL, 1 | 2 | 4, default 1) 16-byte accesses per lane, stream and loop trip of the merged
+ *                              solver's update kernels.
+ *   BP5_TUNE_UPDATE_FLAT       (env BP5_UPDATE_FLAT, default 1) streaming kernels without a reduction (update kernels, vector updates)
+ *                              are launched with ONE trip per workgroup instead of a capped grid-stride grid: the stores of a capped
+ *                              grid drift apart and lose 15-35 % of the HBM write rate (profiles/r4: hbm_sweep).
+ *   BP5_TUNE_UPDATE_NT         (env BP5_UPDATE_NT, -1 | 0 | 1, default -1) non-temporal accesses to v and x in the update kernels:
+ *                              -1 = the library's default (on at every size: -0.9 % per iteration at 1e8 DoFs, -1.2 % at 1e7). */
+enum { BP5_TUNE_LATTICE_INDICES = 0, BP5_TUNE_EARLY_GATHER = 1, BP5_TUNE_COMBINE_SIGNAL = 2, BP5_TUNE_BOUNDARY_FIRST = 3,
+       BP5_TUNE_FOLD_SMALL = 4, BP5_TUNE_UPDATE_UNROLL = 5, BP5_TUNE_UPDATE_FLAT = 6, BP5_TUNE_UPDATE_NT = 7, BP5_TUNE_COUNT = 8 };
+int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value);
+int bp5_mf_get_tuning(const bp5_mf *mf, int knob, int *value);
+/* 1 when the in-launch stream wait-value schedules are available on this handle (capability + self-check, see BP5_TUNE_BOUNDARY_FIRST);
+ * creates the handle's communication stream if it does not exist yet */
+int bp5_mf_wait_value_available(bp5_mf *mf, int *available);
 /* facts about the block kernel's plan for this handle (builds it): number of cell blocks, longest run-length list of a
  * block, and whether the packed one-u16-per-DoF index form is available (<= 128 runs per block; brick-major numbering
  * gives ~30, a slab's boundary bricks with their ghost rows ~70) -- every rank of a multi-GPU run should report 1 */

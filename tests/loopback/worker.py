@@ -79,13 +79,13 @@ def main():
         solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_again")
         solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped_again")
         solve(pkg.SolverCG, 1, True, "plain_overlapped")
-        os.environ["BP5_EARLY_GATHER"] = "0"       # the ghost gather of p AFTER the update kernel instead of underneath it: the same bits
+        op.mf_data.set_tuning("early_gather", 0)   # the ghost gather of p AFTER the update kernel instead of underneath it: the same bits
         solve(pkg.SolverCGFullMerge, 0, True, "merged_unsplit_late_gather")
         solve(pkg.SolverCGFullMerge, 1, True, "merged_overlapped_late_gather")
-        del os.environ["BP5_EARLY_GATHER"]
-        os.environ["BP5_COMBINE_SIGNAL"] = "1"     # the default schedule with ONE combine launch (ghost rows first, stream wait-value): the same bits
+        op.mf_data.set_tuning("early_gather", 1)
+        op.mf_data.set_tuning("combine_signal", 1)  # the default schedule with ONE combine launch (ghost rows first, stream wait-value): the same bits
         solve(pkg.SolverCGFullMerge, 2, True, "merged_default_one_combine_launch")
-        del os.environ["BP5_COMBINE_SIGNAL"]
+        op.mf_data.set_tuning("combine_signal", 0)
         res["norms"] = np.asarray(norms)
         if stop_tol > 0.0:
             # tolerance stop across ranks: every rank sees the same all-reduced residual, the device-side convergence flag fires on all of them in

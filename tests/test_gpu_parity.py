@@ -506,19 +506,21 @@ def test_lattice_blocks_need_no_index_stream(p, cells, block, kw):
     """Structured bricks with brick-major numbering (the library's own generator; partial bricks at the mesh edges; the ghost-touching layer
     of a slab with its block-major ghost plane): every block is recognised as a LATTICE block (topologically, then verified entry by entry on
     the host), and the kernel build that computes list slots and DoFs in closed form -- no per-DoF index stream -- gives bitwise the result
-    of the packed-index build (BP5_LATTICE_INDICES=0) and matches the atomic pencil kernel."""
+    of the packed-index build (BP5_TUNE_LATTICE_INDICES = 0) and matches the atomic pencil kernel."""
     torch = _t()
     mesh = pkg.BrickMesh(p, cells, h=0.2, deform_amp=0.03, cell_block=block, dof_numbering=1, cell_block_order=1, **kw)
     ops = []
-    for lattice in ("1", "0"):
-        os.environ["BP5_LATTICE_INDICES"] = lattice                 # read when the block plan is built
+    for lattice in (1, 0):
         op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+        op.mf_data.set_tuning("lattice_indices", lattice)          # a knob of the HANDLE (two handles of one process differ here), fixed once the plan is built
         op.mf_data.set_apply_variant(56)
         op.mf_data.set_block_workgroups(8)
         nb, _, packed = op.mf_data.block_plan_info()
-        assert packed and op.mf_data.block_plan_lattice() == (nb if lattice == "1" else 0)
+        assert packed and op.mf_data.block_plan_lattice() == (nb if lattice else 0)
+        assert op.mf_data.get_tuning("lattice_indices") == lattice
+        with pytest.raises(pkg.BP5Error):
+            op.mf_data.set_tuning("lattice_indices", 1 - lattice)  # the plan exists: refused instead of silently ignored
         ops.append(op)
-    del os.environ["BP5_LATTICE_INDICES"]
     n = mesh.n_owned + mesh.n_ghost
     g = torch.Generator(device="cuda:0").manual_seed(9)
     src = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5

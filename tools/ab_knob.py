@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""merged CG per-iteration time with a knob of the library at several values, interleaved in ONE process: an environment variable the library
-reads per solve (--knob BP5_EARLY_GATHER) or a setter of MatrixFree (--knob streaming -> mf.set_streaming(int(value)))
+"""merged CG per-iteration time with a knob of the library at several values, interleaved in ONE process: a tuning knob of the handle
+(--knob update_flat -> mf.set_tuning("update_flat", int(value)); several knobs at once: --knob update_flat,update_unroll --values 0,4 1,1 1,2)
+or a setter of MatrixFree (--knob streaming -> mf.set_streaming(int(value)))
 usage: python tools/ab_knob.py --knob streaming --values 0 1 --cells 54 54 54 --cell-block 4 4 2"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,10 +23,11 @@ print("bricks", op.mf_data.block_plan_info()[0], "dofs", mesh.n_owned, flush=Tru
 res = {}
 for rnd in range(a.rounds + 1):
     for val in a.values:
-        if a.knob.startswith("BP5_"):
-            os.environ[a.knob] = val
-        else:
-            getattr(op.mf_data, "set_" + a.knob)(int(val))
+        for kn, v in zip(a.knob.split(","), val.split(",")):
+            if kn in op.mf_data.TUNE:
+                op.mf_data.set_tuning(kn, int(v))
+            else:
+                getattr(op.mf_data, "set_" + kn)(int(v))
         ctl = pkg.IterationNumberControl(a.iters, 0.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

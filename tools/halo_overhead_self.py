@@ -64,12 +64,12 @@ res = {}
 all_modes = {"auto": "slab + exchange, automatic", "overlapped": "slab + exchange, overlapped", "launches": "slab + exchange, overlapped (two launches)",
              "sequential": "slab + exchange, sequential", "none": "same size, one rank, no exchange"}
 for name in [all_modes[m] for m in args.modes.split(",")]:
-    os.environ["BP5_BOUNDARY_FIRST"] = "launches" if "two launches" in name else "signal"   # read when the handle creates its communication stream
     if name.startswith("slab"):
         comm, msh = pkg.Communicator(0, 1), mesh
     else:
         comm, msh = None, pkg.BrickMesh(p, (n, n, layers), h=1.0 / n, **kw)
     op = pkg.PoissonOperator(msh, 0, pkg.COEF_STEP64, comm=comm)
+    op.mf_data.set_tuning("boundary_first", 0 if "two launches" in name else 1)
     if name.startswith("slab"):
         op.mf_data.set_overlap(0 if name.endswith("sequential") else 2 if name.endswith("automatic") else 1)
     b = op.assemble_rhs()
