@@ -874,7 +874,7 @@ static int effective_variant(bp5_mf *mf, uint32_t c0, uint32_t c1)
 static bool variant_overwrites(const bp5_mf *mf, int ev)
 {
   const int v = ev % 100;
-  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 62)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
+  return ev < 100 && ((v >= 10 && v <= 14) || (v >= 48 && v <= 63)) && !(mf->geometry_mode == BP5_GEOM_AFFINE && mf->degree != 4);
 }
 
 static int launch_apply_impl(bp5_mf *mf, const double *coef, const double *src, double *dst, uint32_t c0, uint32_t c1, bool overwrite)
@@ -1393,7 +1393,7 @@ static int phases_begin(bp5_mf *mf, double *dst, bool overwrite, ApplyPhases &ph
 {
   ph.user_variant = mf->apply_variant;
   const int ev = effective_variant(mf, 0, mf->n_cells);
-  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61 || ev % 100 == 62) && block_lpc(mf->degree) != 0 && (mf->degree == 4 || ev % 100 == 56);
+  ph.block = ev < 100 && (ev % 100 == 56 || ev % 100 == 48 || ev % 100 == 49 || ev % 100 == 60 || ev % 100 == 61 || ev % 100 == 62 || ev % 100 == 63) && block_lpc(mf->degree) != 0 && (mf->degree == 4 || ev % 100 == 56);
   ph.overwrite = false;
   if (ph.block) {
     BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &ph.dp));
@@ -1786,7 +1786,7 @@ static int cg_solve_impl(bp5_mf *mf, const double *coef, bp5_vmult_fn user, void
   const bool dist_solve = mf->comm && !mf->neighbors.empty();
   bool split = false, split_possible = false, late = false;
   if (!user && mf->cg_fusion && (plain || !diag) && block_lpc(mf->degree) != 0 && mf->geometry_mode == BP5_GEOM_MERGED6 &&
-      effective_variant(mf, 0, mf->n_cells) == 56) {
+      (effective_variant(mf, 0, mf->n_cells) == 56 || (mf->degree == 4 && effective_variant(mf, 0, mf->n_cells) == 63))) {
     bp5_mf::DevPlan *dp = nullptr;
     BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp));
     fused_dots = dp->packed && dp->covers_all && (dp->n_shared == 0 || dp->cr_tile);

@@ -321,7 +321,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
     mf->n_cus = prop.multiProcessorCount;
   }
-  const int wg_per_cu = ((ABL & 2048) && !(ABL & 8388608) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (the Helmholtz build: two per CU, registers)
+  const int wg_per_cu = ((ABL & 2048) && !(ABL & 8388608) && !BP5_ROLL_TWO(ABL) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (the Helmholtz build: two per CU, registers)
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);
@@ -805,7 +805,8 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
     // 60 = 56 with the brick's src staged once in LDS (cells gather from LDS; needs the packed indices)
     // 61 = 56 with non-temporal metric loads (A/B: the once-read metric stream then evicts less of a brick's src from L2)
     // 62 = 56 with ds_add_f64 for the accumulation into the LDS vector (A/B)
-    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56 || variant == 60 || variant == 61 || variant == 62) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
+    // 63 = 56 with the rolling metric prefetch (BlockPass::ROLL; lattice blocks only) -- libbp5_timing.so only: a measured loss (profiles/r4 d_*)
+    if constexpr (DEG == 4) if (variant == 48 || variant == 49 || variant == 56 || variant == 60 || variant == 61 || variant == 62 || variant == 63) { if (block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) {
         struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; m->combine_csr = false; } } reset{mf};
         mf->combine_csr = variant == 48;
         bp5_mf::DevPlan *dp_ = nullptr;
@@ -826,8 +827,20 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite);
         }
         constexpr int LATT = 16777216; // every block a lattice block: closed-form indices, no per-DoF index stream
-        const bool lattice = variant == 56 && dp_->packed && dp_->lattice && dp_->n_lattice_blocks == dp_->n_groups;
+        const bool lattice = (variant == 56 || variant == 63) && dp_->packed && dp_->lattice && dp_->n_lattice_blocks == dp_->n_groups;
         const bool ntm = streaming_accesses(mf); // non-temporal metric loads
+#ifndef BP5_TIMING_BUILDS
+        if (variant == 63) return fail(BP5_ERR_INVALID, "variant 63 lives in libbp5_timing.so");
+#else
+        constexpr int ROLL = 67108864;
+        if (variant == 63) {
+          if (!lattice || coll) return fail(BP5_ERR_UNSUPPORTED, "variant 63 (rolling metric prefetch) needs lattice blocks and Gauss quadrature");
+          if (mf->fuse.on) return ntm ? launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT + 32768 + ROLL>(mf, coef, src, dst, overwrite)
+                                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT + ROLL>(mf, coef, src, dst, overwrite);
+          return ntm ? launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT + 32768 + ROLL>(mf, coef, src, dst, overwrite)
+                     : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT + ROLL>(mf, coef, src, dst, overwrite);
+        }
+#endif
         if (mf->fuse.on) { // the solver asked for the fused dot products (only ever with the packed default shape)
           if (!dp_->packed || variant != 56) return fail(BP5_ERR_INVALID, "fused dot products need the packed block kernel");
           if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT + 32768>(mf, coef, src, dst, overwrite);
@@ -864,6 +877,9 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
     BP5_CASE(4, 53) { if (c0 == 0 && c1 == mf->n_cells) return coll ? launch_block_t<4, true, 25, 2048>(mf, coef, src, dst, overwrite) : launch_block_t<4, false, 25, 2048>(mf, coef, src, dst, overwrite);
       return fail(BP5_ERR_INVALID, "variant 53 needs the whole cell range"); }
 #ifdef BP5_TIMING_BUILDS
+    BP5_CASE(4, 64) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 16777216>(mf, coef, src, dst, true);              // the lattice build (reference point of the two probes below)
+    BP5_CASE(4, 65) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 16777216 + 33554432>(mf, coef, src, dst, true);   // ... metric as whole aligned lines, 12 instructions
+    BP5_CASE(4, 66) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 16777216 + 134217728>(mf, coef, src, dst, true);  // ... tails paired, 15 instructions
     BP5_CASE(4, 87) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 65536>(mf, coef, src, dst, true);  // variant 56 with plain (not non-temporal) stores
     BP5_CASE(4, 91) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 1>(mf, coef, src, dst, true);  // variant 56 without write-out (and combine)
     BP5_CASE(4, 93) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 2>(mf, coef, src, dst, true);  // ... without metric loads

@@ -61,6 +61,22 @@ __device__ __forceinline__ void load_pencil(const double *base, int ab, double (
   if constexpr (n & 1) S[n - 1] = NT ? __builtin_nontemporal_load(base + (n / 2) * (2 * n * n) + ab) : base[(n / 2) * (2 * n * n) + ab];
 }
 
+// pieces of load_pencil: pair m (qi = 2m, 2m + 1) and the unpaired last qi of an odd n -- the rolling metric prefetch of the block kernel
+// (BlockPass::ROLL) refills a pencil piece by piece, each piece right after the quadrature-point loop has consumed it
+template <int n, bool NT = false>
+__device__ __forceinline__ void load_pencil_pair(const double *base, int ab, int m, double &s0, double &s1)
+{
+  const bp5_d2u *q = reinterpret_cast<const bp5_d2u *>(base + m * (2 * n * n) + 2 * ab);
+  const bp5_d2u v = NT ? __builtin_nontemporal_load(q) : *q;
+  s0 = v.x;
+  s1 = v.y;
+}
+template <int n, bool NT = false>
+__device__ __forceinline__ double load_pencil_tail(const double *base, int ab)
+{
+  return NT ? __builtin_nontemporal_load(base + (n / 2) * (2 * n * n) + ab) : base[(n / 2) * (2 * n * n) + ab];
+}
+
 struct ApplyArgs {
   const uint32_t *l2g;
   const double *coef;
@@ -1231,11 +1247,11 @@ struct BlockPlan {
 };
 
 // register set of one pass (cell ids, positions, gathered values, metric)
-template <int n, bool AFFINE, int NPL = 6>
+template <int n, bool AFFINE, int NPL = 6, bool ROLL = false>
 struct PassRegs {
   uint16_t ps[n];
   double u[n];
-  double S[AFFINE ? 1 : NPL][n]; // affine: one scalar plane ... (NPL = 7: the Helmholtz build's mass plane behind the six merged ones)
+  double S[(AFFINE || ROLL) ? 1 : NPL][ROLL ? 1 : n]; // affine: one scalar plane ... (NPL = 7: the Helmholtz build's mass plane behind the six merged ones; ROLL: the metric lives in ONE register set shared by all passes)
   double Gc[AFFINE ? 6 : 1];   // ... and the cell's constant K K^T
   uint32_t idx[n];
   uint32_t ent; // pass_cell entry
@@ -1279,7 +1295,15 @@ struct BlockPass {
   // cell skips both (one ballot / one barrier-with-or per pass)
   static constexpr bool HANG = (ABL & 2097152) != 0;
   static_assert(!HANG || (ABL & 8192) != 0, "hanging-node build: sequential tiles");
-  using R = PassRegs<n, AFFINE, NPL>;
+  // ROLL: rolling metric prefetch.  The metric of pass q + 1 is loaded INTO THE REGISTERS OF PASS q's METRIC, piece by piece, each piece right
+  // after the quadrature-point loop of pass q has consumed it: the six planes of the next pass are in flight during integrate, accumulation,
+  // write-out and the next evaluate -- a whole pass ahead -- at the register cost of the single-buffered build (three workgroups per CU).
+  // Without it a wave has loads in flight during evaluate only.  MEASURED, NOT ADOPTED (profiles/r4 d_*): held for a whole pass the six planes cost
+  // 50 more VGPRs than the three-waves-per-SIMD budget has (210-221 against 168); at two workgroups per CU the kernel takes 2.72 against 2.40 ms, capped
+  // at 168 registers it spills and takes 4.73 -- this kernel lives on its twelve waves per CU, not on its prefetch depth.  Kept for libbp5_timing.so
+  static constexpr bool ROLL = (ABL & 67108864) != 0;
+  static_assert(!ROLL || (((ABL & 2048) != 0) && ((ABL & 8192) != 0) && !AFFINE), "rolling prefetch: single-buffered build, sequential tiles, plane geometry");
+  using R = PassRegs<n, AFFINE, NPL, ROLL>;
   // all lanes of a cell slot sit in one wave when LPC divides 64: the tile exchanges then need no block barrier
   static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
   // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
@@ -1337,8 +1361,22 @@ struct BlockPass {
     if constexpr (HANG) r.mask = a.hang_mask[cell];
     if constexpr (!SINGLE) issue_metric(a, r, abm);
   }
+  // ROLL: the whole metric of the cell named by `ent` (first pass of a workgroup only)
+  static __device__ __forceinline__ void issue_metric_roll(const ApplyArgs &a, uint32_t ent, int abm, double (&S)[NPL][n])
+  {
+    const double *cf = a.coef + (uint64_t)(ent & 0x7fffffffu) * a.cell_stride;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      if constexpr (ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) S[pl][i] = 1.0 + pl + i;
+      } else
+        load_pencil<n, (ABL & 32768) != 0>(cf + pl * a.plane_stride, abm, S[pl]);
+    }
+  }
   static __device__ __forceinline__ void issue_metric(const ApplyArgs &a, R &r, int abm)
   {
+    if constexpr (ROLL) return;
     const uint64_t cell = r.ent & 0x7fffffffu;
     const double *cf = a.coef + cell * a.cell_stride; // cell base (pair layout, load_pencil)
     if constexpr (AFFINE) {
@@ -1346,6 +1384,38 @@ struct BlockPass {
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl) r.Gc[pl] = a.gcell[(uint64_t)pl * a.n_cells_total + cell];
     } else {
+#ifdef BP5_TIMING_BUILDS
+      // timing-only probes of the metric stream's SHAPE (wrong values by construction; profiles/r4): what would a layout be worth
+      //   33554432   in which every wave-instruction reads 1 KB of whole, aligned lines (all 64 lanes load 16 B at consecutive addresses: 12 instead of 18
+      //              instructions per pass, no partial line, no 8-byte tail loads)
+      //   134217728  in which the unpaired last entries of two planes share one 16-byte load (15 instead of 18 instructions, same lines)
+      if constexpr ((ABL & 33554432) != 0 && (n & 1)) {
+        const uint64_t cell0 = (uint64_t)__builtin_amdgcn_readfirstlane((int)cell);
+        const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          const double *base = a.coef + pl * a.plane_stride + ((cell0 * a.cell_stride) & ~(uint64_t)15);
+#pragma unroll
+          for (int m = 0; m < n / 2; ++m) {
+            const bp5_d2u v = *reinterpret_cast<const bp5_d2u *>(base + (m * 64 + lane) * 2);
+            r.S[pl][2 * m] = v.x;
+            r.S[pl][2 * m + 1] = v.y;
+          }
+          r.S[pl][n - 1] = r.S[pl][0] + 1.0;
+        }
+        return;
+      }
+      if constexpr ((ABL & 134217728) != 0 && (n & 1) && NPL == 6) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+          for (int m = 0; m < n / 2; ++m) load_pencil_pair<n>(cf + pl * a.plane_stride, abm, m, r.S[pl][2 * m], r.S[pl][2 * m + 1]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl += 2) load_pencil_pair<n>(cf + pl * a.plane_stride, abm, n / 2, r.S[pl][n - 1], r.S[pl + 1][n - 1]); // (reads into the next cell's first pairs: same lines)
+        return;
+      }
+#endif
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
         if constexpr (ABL & 2) {
@@ -1404,9 +1474,10 @@ struct BlockPass {
   // one pass: compute with `cur`, keep the loads of `nxt` in flight.  Returns nothing; all
   // block bookkeeping is done by the caller.
   static __device__ __forceinline__ void run(const ApplyArgs &a, const ShapeArg<n> &sh, R &cur, R &nxt, double *T, double *acc, int a_, int b_,
-                                             int n_rounds, int abm, unsigned long long (&ph)[8], unsigned long long &tprev, double &energy)
+                                             int n_rounds, int abm, unsigned long long (&ph)[8], unsigned long long &tprev, double &energy,
+                                             double (&Sr)[ROLL ? NPL : 1][ROLL ? n : 1])
   {
-    if constexpr (SINGLE) issue_metric(a, cur, abm);
+    if constexpr (SINGLE && !ROLL) issue_metric(a, cur, abm);
     BP5_STAMP(0) // issue of this pass's loads
     if constexpr (SEQ) {
 #define T1(k, j, i) T[(k) * L::PS + (j) * L::RS + (i)]
@@ -1513,27 +1584,54 @@ struct BlockPass {
       BP5_STAMP(1)
       if constexpr (!PACK) issue_gather(a, nxt); // PACK: after the pass, once the next block's run table is parked
       BP5_STAMP(2)
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
+      auto qpoint = [&](int i, auto &&SM) { // SM(plane): the metric entry of this lane's quadrature point i
         const double x0 = q0[i], x1 = q1[i], x2 = q2[i];
         if constexpr (AFFINE) {
-          const double sc = cur.S[0][i];
+          const double sc = SM(0);
           q0[i] = sc * (cur.Gc[0] * x0 + cur.Gc[3] * x1 + cur.Gc[4] * x2);
           q1[i] = sc * (cur.Gc[3] * x0 + cur.Gc[1] * x1 + cur.Gc[5] * x2);
           q2[i] = sc * (cur.Gc[4] * x0 + cur.Gc[5] * x1 + cur.Gc[2] * x2);
         } else {
-          q0[i] = cur.S[0][i] * x0 + cur.S[3][i] * x1 + cur.S[4][i] * x2;
-          q1[i] = cur.S[3][i] * x0 + cur.S[1][i] * x1 + cur.S[5][i] * x2;
-          q2[i] = cur.S[4][i] * x0 + cur.S[5][i] * x1 + cur.S[2][i] * x2;
+          q0[i] = SM(0) * x0 + SM(3) * x1 + SM(4) * x2;
+          q1[i] = SM(3) * x0 + SM(1) * x1 + SM(5) * x2;
+          q2[i] = SM(4) * x0 + SM(5) * x1 + SM(2) * x2;
         }
         // fused CG: src . (A src) is the sum over cells and quadrature points of ghat^T S ghat -- everything is in
         // registers here, the dot product costs no memory traffic at all
         if constexpr ((ABL & 1048576) != 0) { if (act) energy += x0 * q0[i] + x1 * q1[i] + x2 * q2[i]; }
         if constexpr (HELM) {
           const double uq = um[i];
-          um[i] = cur.S[6][i] * uq; // submit_value(coef * get_value(q)), JxW folded into the plane
+          um[i] = SM(6) * uq; // submit_value(coef * get_value(q)), JxW folded into the plane
           if constexpr ((ABL & 1048576) != 0) { if (act) energy += uq * um[i]; }
         }
+      };
+      if constexpr (ROLL) {
+        // consume the metric pair by pair and refill each pair with the NEXT pass's values right away (same registers)
+        const double *cfn = a.coef + (uint64_t)(nxt.ent & 0x7fffffffu) * a.cell_stride;
+        constexpr bool NTM = (ABL & 32768) != 0;
+#pragma unroll
+        for (int m = 0; m < n / 2; ++m) {
+          qpoint(2 * m, [&](int pl) { return Sr[pl][2 * m]; });
+          qpoint(2 * m + 1, [&](int pl) { return Sr[pl][2 * m + 1]; });
+          __builtin_amdgcn_sched_barrier(0); // the refill must not be hoisted above the last use of the registers it overwrites (it would need new ones)
+          if constexpr (!(ABL & 2)) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) load_pencil_pair<n, NTM>(cfn + pl * a.plane_stride, abm, m, Sr[pl][2 * m], Sr[pl][2 * m + 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (n & 1) {
+          qpoint(n - 1, [&](int pl) { return Sr[pl][n - 1]; });
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!(ABL & 2)) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) Sr[pl][n - 1] = load_pencil_tail<n, NTM>(cfn + pl * a.plane_stride, abm);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < n; ++i) qpoint(i, [&](int pl) { return cur.S[pl][i]; });
       }
       BP5_STAMP(3)
       double yy[n];
@@ -1812,8 +1910,11 @@ struct BlockPass {
   }
 };
 
+// the rolling-prefetch builds (BlockPass::ROLL; libbp5_timing.so only) take 210-221 VGPRs: two workgroups per CU (capped at three waves per SIMD they spill
+// 100-150 registers and run at half the speed)
+#define BP5_ROLL_TWO(ABL) (((ABL) & 67108864) != 0)
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 8388608)) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 8388608) && !BP5_ROLL_TWO(ABL)) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;
@@ -1925,9 +2026,11 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
   if constexpr (ABL & 4096) tprev = stamp_now();
   typename BP::R A, B;
+  double Sroll[BP::ROLL ? BP::NPL : 1][BP::ROLL ? n : 1]; // ROLL: the one metric register set, refilled piece by piece (BlockPass::run)
   A.ent = entry(gp);
   B.ent = entry(gp + 1);
   BP::issue_loads(a, bp, A, abm, lane_ok, true);
+  if constexpr (BP::ROLL) BP::issue_metric_roll(a, A.ent, abm, Sroll);
   if constexpr (BP::PACK) {
     // the first block's run table (and lattice table) must be in LDS before the first decode
     uint32_t *const rt0 = run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS);
@@ -2172,7 +2275,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
     prefetch_list();
     BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entA2 = entry(gp + 2);
-    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0]);
+    BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0], Sroll);
     finish_pass();
     BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
@@ -2181,7 +2284,7 @@ __global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 838860
     prefetch_list();
     BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
     const uint32_t entB2 = entry(gp + 2);
-    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0]);
+    BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0], Sroll);
     finish_pass();
     BP5_STAMP(6)
     if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); }

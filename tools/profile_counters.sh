@@ -1,6 +1,7 @@
 #!/bin/bash
 # Extra hardware counters of the dominant kernel of the driver's bench command, one rocprofv3 --pmc pass per counter group (--kernel-trace only):
 #   bash tools/profile_counters.sh <tag> "TCC_HIT_sum TCC_MISS_sum" "LDSBankConflict" ...
+# BENCH_ARGS="--config 4 --degree 8 ..." profiles another workload of bench.py (default: the driver's)
 set -e
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/$tag/g$i -o p --output-format csv -- python3 $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-pass --sustained-iters 0 > $R/gpurun_out/$tag/g$i.log 2>&1 || echo "group $i failed: $grp"
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/$tag/g$i -o p --output-format csv -- python3 $R/bench.py --gpus 1 $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-pass --sustained-iters 0 > $R/gpurun_out/$tag/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 cd $R
 python3 - "$tag" <<'PY'
