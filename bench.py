@@ -4,14 +4,15 @@
   python bench.py --gpus N --steps K --warmup W
 
 A "step" is one CG iteration (operator apply + vector updates + dot products) of the fused solver on the
-p=4, 116^3-cell, 100 544 625-DoF synthetic hex mesh (BASELINE config 3; at N = 1 the whole problem sits on one
-GPU).  W warm-up iterations, then a solve of exactly K iterations is timed between barrier + synchronize pairs,
+p=4, 116x116x120-cell, 104 004 225-DoF synthetic hex mesh (BASELINE config 3; at N = 1 the whole problem sits on one
+GPU; rounds 1-3: 116^3 cells -- 120 layers split into 2, 4 and 8 z-slabs of EQUAL height, 116 gave one of eight ranks 15 layers
+against a mean of 14.5; `--cells 116 116 116` is the old mesh, same DoF/s at N = 1: profiles/r4).  W warm-up iterations, then a solve of exactly K iterations is timed between barrier + synchronize pairs,
 max over ranks (the reference times the whole cg.solve too: bp5/step-64.cu:442-463).  Prints ONE JSON line on rank 0.
 
 N > 1: one rank per GPU, RCCL over xGMI.  Either the caller starts the ranks (torch.distributed.run sets
 RANK/WORLD_SIZE), or this script starts them itself -- as a CHILD process, before anything here touches a GPU.
-Default = STRONG scaling: the SAME 116^3 problem split into N z-slabs (the reference reports the throughput of one
-~1e8-DoF problem spread over its ranks, bp5/step-64.cu:457-461); `--scaling weak` gives every rank a 116^3 slab.
+Default = STRONG scaling: the SAME 116x116x120 problem split into N z-slabs (the reference reports the throughput of one
+~1e8-DoF problem spread over its ranks, bp5/step-64.cu:457-461); `--scaling weak` gives every rank a 116x116x120 slab.
 """
 import argparse
 import json
@@ -25,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HEADLINE_CELLS = (116, 116, 120)  # BASELINE config 3 ("p = 4, ~1e8 DoFs"): 465 x 465 x 481 = 104 004 225 DoFs; 120 cell layers = 2 x 60 = 4 x 30 = 8 x 15
 
 
 def algorithmic_bytes_per_dof(p, n_cells, n_dofs, G=6, I=1, operator_only=False):
@@ -154,7 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, choices=[1, 2, 3, 4, 5], default=None,
                     help="BASELINE.json configuration as ONE flag: 1 = p 2, 8^3 cells, 10 iterations (plumbing); 2 = p 4, 54^3 (1.02e7 DoFs), "
-                         "variable coefficient; 3 = p 4, 116^3 (1.0e8 DoFs; the default, what --gpus N splits); 4 = degree sweep p = 1..8 at ~5e7 "
+                         "variable coefficient; 3 = p 4, 116x116x120 (1.04e8 DoFs; the default, what --gpus N splits into equal z-slabs); 4 = degree sweep p = 1..8 at ~5e7 "
                          "DoFs (value = the degree of --degree, all eight under 'sweep'); 5 = p 6, 61^3, deformed mesh")
     ap.add_argument("--degree", type=int, default=None)
     ap.add_argument("--cells", type=int, nargs=3, default=None,
@@ -197,7 +199,7 @@ def main():
     args = ap.parse_args()
     # BASELINE configurations as one flag each (explicit flags still win)
     cfg = {1: dict(degree=2, cells=[8, 8, 8], steps=10, deform=0.0), 2: dict(degree=4, cells=[54, 54, 54], deform=0.0),
-           3: dict(degree=4, cells=[116, 116, 116], deform=0.0), 4: dict(deform=0.0), 5: dict(degree=6, cells=[61, 61, 61], deform=0.05)}.get(args.config, {})
+           3: dict(degree=4, cells=list(HEADLINE_CELLS), deform=0.0), 4: dict(deform=0.0), 5: dict(degree=6, cells=[61, 61, 61], deform=0.05)}.get(args.config, {})
     for k, v in cfg.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
@@ -260,9 +262,9 @@ def main():
 
     t_setup0 = time.perf_counter()
     p = args.degree
-    # p = 4: the headline size (config 3: 116^3 cells, 100 544 625 DoFs); other degrees: config 4 (~5e7 DoFs)
-    n1 = {**CONFIG_SIZES, 4: 92 if args.config == 4 else 116}[p]
-    base = tuple(args.cells) if args.cells else (n1, n1, n1)
+    # p = 4: the headline size (config 3: 116x116x120 cells, 104 004 225 DoFs); other degrees: config 4 (~5e7 DoFs)
+    n1 = {**CONFIG_SIZES, 4: 92}[p]
+    base = tuple(args.cells) if args.cells else (HEADLINE_CELLS if (p == 4 and args.config != 4) else (n1, n1, n1))
     strong = args.scaling == "strong"
     cells = base if strong else (base[0], base[1], base[2] * world)   # z-slabs either way
     quad = pkg.QUAD_GAUSS if args.quadrature == "gauss" else pkg.QUAD_GLL
@@ -410,7 +412,7 @@ def main():
                                    f"BP5 p={p} {args.quadrature}(p+1) quadrature, {cells[0]}x{cells[1]}x{cells[2]} hex cells, "
                                    f"{n_global} DoFs, coefficient={args.coefficient}, deform={args.deform}, "
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
-                       "baseline_config": args.config if args.config else (3 if (p == 4 and base == (116, 116, 116)) else None),
+                       "baseline_config": args.config if args.config else (3 if (p == 4 and base == HEADLINE_CELLS) else None),
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world} ({args.scaling} scaling)",
                        "cell_block": list(block) if blocked else None, "apply_variant": ev, "cg_dot_products_fused": fused,
                        "cg_dot_products_fused_on_every_rank": fused_all, "cg_dot_products_fused_on_some_rank": fused_any,

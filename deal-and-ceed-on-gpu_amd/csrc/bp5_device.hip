@@ -725,6 +725,22 @@ int get_plan(bp5_mf *mf, int cpt, TeamPlan &tp, bp5_mf::DevPlan **dpo)
   return BP5_OK;
 }
 
+// fixed grid of the fused solver's combine pass: k workgroups per CU (BP5_TUNE_COMBINE_WG_PER_CU, default 16: profiles/r4 h_*; each
+// workgroup walks its tiles two at a time), never more than tiles or free dot-product columns
+static uint32_t combine_grid(bp5_mf *mf, uint32_t tiles)
+{
+  const uint32_t cols = (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u;
+  uint32_t grid = std::min<uint32_t>(tiles, cols);
+  const int k = mf->tune[BP5_TUNE_COMBINE_WG_PER_CU];
+  if (k > 0) {
+    if (!mf->n_cus) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, mf->device) == hipSuccess) mf->n_cus = prop.multiProcessorCount;
+    }
+    grid = std::min<uint32_t>(grid, (uint32_t)k * (uint32_t)std::max(mf->n_cus, 1));
+  }
+  return std::max<uint32_t>(grid, 1u);
+}
 int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window)
 {
   if (!dp->n_shared) return BP5_OK;
@@ -754,7 +770,7 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int w
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = owned_tiles; cr.cg_state = mf->d_st;
       if (mf->fuse.n_cols + 1024u + 8u > (uint32_t)PARTIAL_STRIDE) return fail(BP5_ERR_UNSUPPORTED, "no partial-sum columns left for the combine pass");
-      const uint32_t grid = std::min<uint32_t>(owned_tiles, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u);
+      const uint32_t grid = combine_grid(mf, owned_tiles);
       if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       else hipLaunchKernelGGL((combine_runs_kernel<false, true, false>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
@@ -769,7 +785,7 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int w
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = cgt.x; cr.cg_state = mf->d_st;
       if (mf->fuse.n_cols + 1024u + 8u > (uint32_t)PARTIAL_STRIDE) return fail(BP5_ERR_UNSUPPORTED, "no partial-sum columns left for the combine pass");
-      const uint32_t grid = std::min<uint32_t>(cgt.x, (uint32_t)PARTIAL_STRIDE - mf->fuse.n_cols - 1024u); // 1024 columns stay free for the exchange
+      const uint32_t grid = combine_grid(mf, cgt.x); // (1024 columns stay free for the exchange)
       // pairs of consecutive ordinals pay on long passes; short ones (config 2, the strong-scaling ranks) are latency-bound
       if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       else hipLaunchKernelGGL((combine_runs_kernel<false, true, false>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
@@ -1228,6 +1244,7 @@ static void tuning_from_environment(bp5_mf *mf)
   { const int u = env_int("BP5_UPDATE_UNROLL", 1); mf->tune[BP5_TUNE_UPDATE_UNROLL] = (u == 2 || u == 4) ? u : 1; }
   mf->tune[BP5_TUNE_UPDATE_FLAT] = env_int("BP5_UPDATE_FLAT", 1) != 0;
   { const int v = env_int("BP5_UPDATE_NT", -1); mf->tune[BP5_TUNE_UPDATE_NT] = v < 0 ? -1 : v != 0; }
+  { const int v = env_int("BP5_COMBINE_WG_PER_CU", 16); mf->tune[BP5_TUNE_COMBINE_WG_PER_CU] = (v >= 0 && v <= 32) ? v : 16; }
 }
 extern "C" int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value)
 {
@@ -1238,6 +1255,9 @@ extern "C" int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value)
       break;
     case BP5_TUNE_UPDATE_NT:
       if (value < -1 || value > 1) return fail(BP5_ERR_INVALID, "BP5_TUNE_UPDATE_NT: -1, 0 or 1");
+      break;
+    case BP5_TUNE_COMBINE_WG_PER_CU:
+      if (value < 0 || value > 32) return fail(BP5_ERR_INVALID, "BP5_TUNE_COMBINE_WG_PER_CU: 0 ... 32");
       break;
     case BP5_TUNE_LATTICE_INDICES:
       if (value != 0 && value != 1) return fail(BP5_ERR_INVALID, "switch: 0 or 1");

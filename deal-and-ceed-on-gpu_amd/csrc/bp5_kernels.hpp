@@ -2778,7 +2778,113 @@ __global__ void __launch_bounds__(256) combine_runs_kernel(CombineRuns cr, const
   };
   const uint32_t t_begin = ghost_job ? cr.ghost_tile0 + blockIdx.x : cr.tile0 + bid;
   const uint32_t t_end = ghost_job ? t_begin + 1 : (DOTS ? cr.tile0 + cr.n_tiles : cr.tile0 + blockIdx.x + 1);
-  for (uint32_t tile = t_begin; tile < t_end; tile += (nblk ? nblk : 1u)) {
+  if constexpr (DOTS && PAIR) {
+    // Long passes (round 4): the pass is a chain of dependent memory latencies per tile (run records -> slot bases -> partials), at full occupancy
+    // -- so a workgroup takes its tiles TWO at a time: the records of both are staged behind one barrier, the slot bases of both are loaded
+    // together, then the partials (and r) of both.  Same tiles per workgroup, same order of the sums and of the dot-product terms: same bits.
+    if (!ghost_job) {
+      __shared__ uint32_t s2_start[COMBINE_TILE + 2], s2_dof0[COMBINE_TILE + 1], s2_soff[COMBINE_TILE + 2];
+      const uint32_t step = nblk ? nblk : 1u;
+      for (uint32_t tile = t_begin; tile < t_end; tile += 2u * step) {
+        const uint32_t tl[2] = {tile, tile + step};
+        const bool have[2] = {true, tile + step < t_end};
+        uint32_t cntv[2] = {0u, 0u};
+        __syncthreads(); // the staging arrays of the previous batch are no longer read
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          if (!have[x]) continue;
+          uint32_t *sst = x ? s2_start : s_start, *sso = x ? s2_soff : s_soff, *sd0 = x ? s2_dof0 : s_dof0;
+          const uint32_t r_lo = cr.tile_run[tl[x]], r_hi = cr.tile_run[tl[x] + 1];
+          cntv[x] = r_hi - r_lo + 1;
+          for (uint32_t j = threadIdx.x; j <= cntv[x]; j += 256) {
+            sst[j] = cr.start[r_lo + j];
+            sso[j] = cr.soff[r_lo + j];
+            if (j < cntv[x]) sd0[j] = cr.dof0[r_lo + j];
+          }
+        }
+        __syncthreads();
+        // per tile: this thread's two consecutive ordinals
+        uint32_t lov[2], jv[2], bv[2], ev[2], gv[2], iv[2];
+        bool dirv[2], pairv[2], livev[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const uint32_t *sst = x ? s2_start : s_start, *sso = x ? s2_soff : s_soff, *sd0 = x ? s2_dof0 : s_dof0;
+          iv[x] = tl[x] * (uint32_t)COMBINE_TILE + 2u * threadIdx.x;
+          livev[x] = have[x] && iv[x] < cr.n_shared;
+          lov[x] = jv[x] = bv[x] = ev[x] = gv[x] = 0u; dirv[x] = pairv[x] = false;
+          if (!livev[x]) continue;
+          uint32_t lo = 0, hi = cntv[x]; // invariant: start[lo] <= i < start[hi]
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sst[mid] <= iv[x]) lo = mid; else hi = mid;
+          }
+          lov[x] = lo; jv[x] = iv[x] - sst[lo]; bv[x] = sso[lo]; ev[x] = sso[lo + 1];
+          gv[x] = (sd0[lo] & 0x7fffffffu) + jv[x];
+          dirv[x] = (sd0[lo] & 0x80000000u) != 0;
+          pairv[x] = iv[x] + 1 < cr.n_shared && iv[x] + 1 < sst[lo + 1];
+        }
+        // slot bases of both tiles, then the partials and r of both (pairs inside one run; the rare pair that straddles two runs below)
+        uint32_t sl[2][4];
+        bp5_d2u pq[2][4], rr[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const uint32_t nq = ev[x] - bv[x];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sl[x][q] = (livev[x] && pairv[x] && (uint32_t)q < nq) ? cr.slots[bv[x] + q] : 0u;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const uint32_t nq = ev[x] - bv[x];
+          const bool on = livev[x] && pairv[x];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pq[x][q] = (on && (uint32_t)q < nq) ? *reinterpret_cast<const bp5_d2u *>(partial + sl[x][q] + jv[x]) : bp5_d2u{0.0, 0.0};
+          rr[x] = bp5_d2u{0.0, 0.0};
+          if (on && cr.cg_r && gv[x] >= dof_lo && gv[x] < dof_hi) { // (the rows of this launch; r is read at owned rows only)
+            if (gv[x] + 1 < cr.n_owned) rr[x] = *reinterpret_cast<const bp5_d2u *>(cr.cg_r + gv[x]);
+            else if (gv[x] < cr.n_owned) rr[x].x = cr.cg_r[gv[x]];
+          }
+        }
+        auto finish_r = [&](uint32_t g, bool dirichlet, double sv, double ri) { // finish() with r[g] loaded ahead (same arithmetic, same order)
+          if (g < dof_lo || g >= dof_hi) return;
+          double vi = sv;
+          if (dirichlet) {
+            vi = cr.cg_p[g];
+            if (g < cr.n_owned) ds[0] += vi * (vi - sv);
+          }
+          dst[g] = vi;
+          if (g < cr.n_owned) { ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri; }
+        };
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          if (!livev[x]) continue;
+          const uint32_t *sso = x ? s2_soff : s_soff, *sd0 = x ? s2_dof0 : s_dof0;
+          if (pairv[x]) {
+            const uint32_t nq = ev[x] - bv[x];
+            bp5_d2u sum{0.0, 0.0};
+            if (nq > 0) {
+              sum = pq[x][0];
+              if (nq > 1) { sum.x += pq[x][1].x; sum.y += pq[x][1].y; }
+              if (nq > 2) { sum.x += pq[x][2].x; sum.y += pq[x][2].y; }
+              if (nq > 3) { sum.x += pq[x][3].x; sum.y += pq[x][3].y; }
+              for (uint32_t q = bv[x] + 4; q < ev[x]; ++q) {
+                const bp5_d2u t2 = *reinterpret_cast<const bp5_d2u *>(partial + cr.slots[q] + jv[x]);
+                sum.x += t2.x; sum.y += t2.y;
+              }
+            }
+            finish_r(gv[x], dirv[x], sum.x, rr[x].x);
+            finish_r(gv[x] + 1, dirv[x], sum.y, rr[x].y);
+          } else {
+            finish(gv[x], dirv[x], sum1(bv[x], ev[x], jv[x]));
+            if (iv[x] + 1 < cr.n_shared) { // first ordinal of the next run
+              const uint32_t l2 = lov[x] + 1, b2 = sso[l2], e2 = sso[l2 + 1];
+              finish(sd0[l2] & 0x7fffffffu, (sd0[l2] & 0x80000000u) != 0, sum1(b2, e2, 0u));
+            }
+          }
+        }
+      }
+    }
+  }
+  for (uint32_t tile = t_begin; tile < ((DOTS && PAIR && !ghost_job) ? t_begin : t_end); tile += (nblk ? nblk : 1u)) {
     if constexpr (DOTS) __syncthreads(); // the staging arrays of the previous tile are no longer read
     const uint32_t r_lo = cr.tile_run[tile], r_hi = cr.tile_run[tile + 1]; // inclusive range, r_hi - r_lo <= COMBINE_TILE
     const uint32_t cnt = r_hi - r_lo + 1;

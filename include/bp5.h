@@ -278,9 +278,13 @@ int bp5_mf_set_streaming(bp5_mf *mf, int policy);
  *                              are launched with ONE trip per workgroup instead of a capped grid-stride grid: the stores of a capped
  *                              grid drift apart and lose 15-35 % of the HBM write rate (profiles/r4: hbm_sweep).
  *   BP5_TUNE_UPDATE_NT         (env BP5_UPDATE_NT, -1 | 0 | 1, default -1) non-temporal accesses to v and x in the update kernels:
- *                              -1 = the library's default (on at every size: -0.9 % per iteration at 1e8 DoFs, -1.2 % at 1e7). */
+ *                              -1 = the library's default (on at every size: -0.9 % per iteration at 1e8 DoFs, -1.2 % at 1e7).
+ *   BP5_TUNE_COMBINE_WG_PER_CU (env BP5_COMBINE_WG_PER_CU, 0 ... 32, default 16) workgroups per CU of the fused solver's combine pass (a fixed grid that walks
+ *                              the tiles of brick-surface DoFs, one dot-product column per workgroup); 0 = as many workgroups as columns are free
+ *                              (rounds 2-3).  The dot products are summed over another column layout (rounding-level differences), v is the same bits. */
 enum { BP5_TUNE_LATTICE_INDICES = 0, BP5_TUNE_EARLY_GATHER = 1, BP5_TUNE_COMBINE_SIGNAL = 2, BP5_TUNE_BOUNDARY_FIRST = 3,
-       BP5_TUNE_FOLD_SMALL = 4, BP5_TUNE_UPDATE_UNROLL = 5, BP5_TUNE_UPDATE_FLAT = 6, BP5_TUNE_UPDATE_NT = 7, BP5_TUNE_COUNT = 8 };
+       BP5_TUNE_FOLD_SMALL = 4, BP5_TUNE_UPDATE_UNROLL = 5, BP5_TUNE_UPDATE_FLAT = 6, BP5_TUNE_UPDATE_NT = 7, BP5_TUNE_COMBINE_WG_PER_CU = 8,
+       BP5_TUNE_COUNT = 9 };
 int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value);
 int bp5_mf_get_tuning(const bp5_mf *mf, int knob, int *value);
 /* 1 when the in-launch stream wait-value schedules are available on this handle (capability + self-check, see BP5_TUNE_BOUNDARY_FIRST);

@@ -218,6 +218,25 @@ def test_bench_launches_its_own_ranks_and_strong_scales_by_default():
         assert parts[0]["neighbors"] == [1] and parts[1]["neighbors"] == [0] and parts[1]["n_ghost"] == 33 * 33
 
 
+def test_bench_default_mesh_splits_into_equal_slabs_at_2_4_8_ranks():
+    """BASELINE config 3 under strong scaling: the default mesh has 120 cell layers, so that 2, 4 and 8 z-slabs hold the same number of
+    cells (116 layers gave one of eight ranks 15 against a mean of 14.5: +3.4 %); owned DoFs differ only by the interface plane the lower rank owns (< 2 %).
+    Host-only dry run of all eight ranks."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(bp5_pkg.ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry-run"], capture_output=True, text=True, timeout=900, cwd=bp5_pkg.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    parts = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in parts] == list(range(8)) and all(d["cells"] == [116, 116, 120] for d in parts)
+    cells = [d["n_cells"] for d in parts]
+    assert max(cells) == min(cells) == 116 * 116 * 15
+    owned = [d["n_owned"] for d in parts]
+    assert sum(owned) == parts[0]["n_global_dofs"] == 465 * 465 * 481 and max(owned) <= 1.02 * sum(owned) / 8
+    assert [d["neighbors"] for d in parts] == [[1]] + [[k - 1, k + 1] for k in range(1, 7)] + [[6]]
+
+
 def test_round2_entry_points_validate_their_arguments_without_a_gpu():
     """The entry points added in round 2 reject NULL handles / callbacks before anything touches a device (status codes, no crash)."""
     L = pkg.lib()

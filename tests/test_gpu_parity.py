@@ -499,6 +499,56 @@ def test_streaming_policy_changes_no_bit():
         mf.set_streaming(2)
 
 
+def test_tuning_knobs_are_fields_of_the_handle_and_change_no_bit():
+    """bp5_mf_set_tuning (round 4; ADVICE r3: the A/B knobs used to be getenv calls on the solve path): the update kernels launched flat (one trip per
+    workgroup, the default) or on the capped grid-stride grid of rounds 1-3, 1 / 2 / 4 accesses per lane, v and x non-temporal or not: the same bits from
+    the merged solve (odd and even iteration counts: both update kernels and the epilogue) and from the vector updates; two handles of one process differ
+    in a knob; bad values are refused."""
+    torch = _t()
+    mesh = pkg.BrickMesh(4, (9, 8, 6), h=0.2, deform_amp=0.03, cell_block=(4, 4, 2), dof_numbering=1, cell_block_order=1)
+    op, op2 = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64), pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)        # the deterministic block kernel (a mesh this small would get the atomic pencil kernel: not reproducible bit for bit)
+    mf.set_block_workgroups(8)
+    assert mf.get_tuning("update_flat") == 1 and mf.get_tuning("update_unroll") == 1 and mf.get_tuning("lattice_indices") == 1
+    op2.mf_data.set_tuning("update_flat", 0)
+    assert op2.mf_data.get_tuning("update_flat") == 0 and mf.get_tuning("update_flat") == 1       # per handle, not per process
+    b = op.assemble_rhs()
+    ref = None
+    for flat, unroll, nt in ((1, 1, -1), (0, 4, 0), (1, 2, 1), (1, 4, 0), (0, 1, 1), (0, 2, -1)):
+        mf.set_tuning("update_flat", flat); mf.set_tuning("update_unroll", unroll); mf.set_tuning("update_nt", nt)
+        xs = []
+        for its in (6, 7):
+            x = op.initialize_dof_vector()
+            pkg.SolverCGFullMerge(pkg.IterationNumberControl(its, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+            xs.append(x)
+        y = torch.arange(mesh.n_owned, dtype=torch.float64, device="cuda:0") * 1e-3
+        v, vb = pkg.Vector(mf), pkg.Vector(mf)
+        v.values.copy_(y); vb.values.copy_(b); v.sadd(0.5, 2.0, vb)
+        if ref is None:
+            ref = (xs, v.values.clone())
+        else:
+            assert torch.equal(xs[0], ref[0][0]) and torch.equal(xs[1], ref[0][1]) and torch.equal(v.values, ref[1])
+    for knob, bad in (("update_unroll", 3), ("update_nt", 2), ("update_flat", 2), ("early_gather", -1), (99, 0)):
+        with pytest.raises(pkg.BP5Error):
+            mf.set_tuning(knob, bad)
+    assert isinstance(mf.wait_value_available(), bool)   # (creates the communication stream and runs the producer / consumer self-check)
+
+
+def test_set_operator_is_refused_once_the_metric_array_is_sized():
+    """bp5_mf_set_operator(BP5_OP_HELMHOLTZ) after the caller sized or filled a six-plane metric array would make every later kernel read a
+    seventh plane out of bounds -- the handle remembers the plane count it handed out and refuses the switch (either direction)."""
+    _t()
+    mesh = pkg.BrickMesh(3, (3, 2, 2), h=0.5)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)         # sized and filled: six planes
+    with pytest.raises(pkg.BP5Error):
+        op.mf_data.set_operator(pkg.OP_HELMHOLTZ)
+    op.mf_data.set_operator(pkg.OP_POISSON)                    # (no change of the plane count: fine)
+    hop = pkg.HelmholtzOperator(mesh, 0, pkg.COEF_STEP64)       # operator first, then seven planes
+    with pytest.raises(pkg.BP5Error):
+        hop.mf_data.set_operator(pkg.OP_POISSON)
+
+
 @pytest.mark.parametrize("p,cells,block,kw", [(4, (9, 8, 6), (4, 4, 4), {}), (4, (8, 8, 12), (4, 4, 2), dict(rank=1, n_ranks=2)), (4, (8, 8, 13), (4, 4, 4), dict(rank=1, n_ranks=3)),
                                             (1, (17, 9, 10), (8, 8, 8), {}), (2, (9, 8, 5), (8, 8, 4), {}), (3, (9, 5, 6), (8, 4, 4), dict(rank=1, n_ranks=2)),
                                             (5, (7, 5, 3), (6, 4, 2), {}), (6, (5, 4, 3), (4, 4, 2), {}), (7, (5, 3, 3), (4, 2, 2), {}), (8, (3, 3, 3), (2, 2, 2), {})])
@@ -1088,7 +1138,7 @@ def test_medium_size_against_c_oracle():
     (4, (54, 54, 54), 0, 0.0, 1, {}, 0),                                                              # BASELINE config 2
     (6, (30, 30, 30), 0, 0.05, 0, {}, 0),                                                             # config 5 shape, reduced
     (4, (86, 84, 82), 0, 0.03, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),   # bench mesh order -> block kernel
-    (4, (116, 116, 116), 0, 0.0, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),  # the bench workload itself (config 3 size on one GPU)
+    (4, (116, 116, 120), 0, 0.0, 1, dict(cell_block=(4, 4, 4), dof_numbering=1, cell_block_order=1), 56),  # the bench workload itself (config 3 size on one GPU; rounds 1-3: 116^3)
     (1, (150, 140, 130), 0, 0.03, 1, {}, 10), (3, (61, 60, 59), 1, 0.03, 1, {}, 10),                  # team-kernel defaults at scale
     (2, (81, 80, 79), 0, 0.03, 0, {}, 0), (5, (33, 32, 31), 1, 0.03, 1, {}, 0), (7, (23, 22, 21), 0, 0.03, 1, {}, 0),
     (8, (20, 19, 18), 1, 0.03, 1, {}, 0),

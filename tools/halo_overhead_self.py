@@ -1,6 +1,6 @@
 """Per-iteration cost of the halo exchange + all-reduce code path on ONE GPU.
 
-The slab a rank > 0 owns in an N-rank run of the bench workload (default: rank 3 of 8 of the 116^3 problem = BASELINE
+The slab a rank > 0 owns in an N-rank run of the bench workload (default: rank 3 of 8 of the 116x116x120 problem = BASELINE
 config 3 under strong scaling, ~1.26e7 DoFs) with its ghost plane exchanged with ITSELF through RCCL (send/recv to self,
 one-rank all-reduce): one plane out and one plane in per exchange, like a middle rank.  Not an xGMI measurement: it shows
 the launch / latency / scheduling overhead the exchange adds to an iteration, overlapped (the library default, exchange on
@@ -47,14 +47,16 @@ ap.add_argument("--solver", choices=["merged", "plain"], default="merged")
 ap.add_argument("--cell-block", type=int, nargs=3, default=[4, 4, 4])
 ap.add_argument("--modes", default="auto,overlapped,launches,sequential,none", help="comma list of: overlapped (boundary-first inside one launch), launches (boundary-first, two launches), sequential, none")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--cells", type=int, nargs=3, default=[116, 116, 120], help="cells of the WHOLE problem (the slab of --rank of --ranks is cut from it)")
 args = ap.parse_args()
-p, n = 4, 116
+p = 4
+n, ny_, nz_ = args.cells
 kw = dict(cell_block=tuple(args.cell_block), dof_numbering=1, cell_block_order=1)
-nz = n * args.ranks if args.weak else n
-m1 = pkg.BrickMesh(p, (n, n, nz), h=1.0 / n, rank=args.rank, n_ranks=args.ranks, **kw)
+nz = nz_ * args.ranks if args.weak else nz_
+m1 = pkg.BrickMesh(p, (n, ny_, nz), h=1.0 / n, rank=args.rank, n_ranks=args.ranks, **kw)
 ng, no = m1.n_ghost, m1.n_owned
-layers = m1.n_cells // (n * n)
-mesh = SimpleNamespace(degree=p, n=p + 1, cells=(n, n, nz), n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
+layers = m1.n_cells // (n * ny_)
+mesh = SimpleNamespace(degree=p, n=p + 1, cells=(n, ny_, nz), n_cells=m1.n_cells, n_interior_cells=m1.n_interior_cells, n_owned=no, n_ghost=ng,
                        n_local=no + ng, n_global_dofs=no, l2g=m1.l2g, coords=m1.coords, global_ids=m1.global_ids, constrained=m1.constrained,
                        n_neighbors=1, neighbor_rank=np.zeros(1, np.int32), send_offsets=np.asarray([0, ng], np.uint32),
                        send_indices=consistent_self_glue(m1), recv_offsets=np.asarray([0, ng], np.uint32),
@@ -67,7 +69,7 @@ for name in [all_modes[m] for m in args.modes.split(",")]:
     if name.startswith("slab"):
         comm, msh = pkg.Communicator(0, 1), mesh
     else:
-        comm, msh = None, pkg.BrickMesh(p, (n, n, layers), h=1.0 / n, **kw)
+        comm, msh = None, pkg.BrickMesh(p, (n, ny_, layers), h=1.0 / n, **kw)
     op = pkg.PoissonOperator(msh, 0, pkg.COEF_STEP64, comm=comm)
     op.mf_data.set_tuning("boundary_first", 0 if "two launches" in name else 1)
     if name.startswith("slab"):
