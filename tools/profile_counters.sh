@@ -24,7 +24,7 @@ for f in sorted(glob.glob(f"gpurun_out/{tag}/g*/**/p_counter_collection.csv", re
         k = (row["Kernel_Name"][:60], row["Counter_Name"])
         per.setdefault(k, []).append(float(row["Counter_Value"]))
     for (k, c), v in sorted(per.items()):
-        if "apply_block_kernel" in k or "combine_runs" in k or "cgm_update" in k:
+        if "apply_" in k or "combine_runs" in k or "cgm_update" in k:
             out.write(f"\"{k}\",{c},{len(v)},{sum(v) / len(v):.4g}\n")
 out.close()
 print(open(f"gpurun_out/{tag}/counters_per_kernel.csv").read())
