@@ -250,7 +250,9 @@ extern "C" int bp5_mf_set_apply_variant(bp5_mf *mf, int v)
     return BP5_OK;
   }
   if (v == 90) return fail(BP5_ERR_INVALID, "apply variant 90 is the hanging-node kernel: the mesh has no constraint masks");
+#ifndef BP5_TIMING_BUILDS
   if (mf->operator_kind == BP5_OP_HELMHOLTZ && v != 0 && !(v == 56 && block_lpc(mf->degree) != 0)) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator runs apply variants 0 (pencil kernel) and 56 (block kernel)");
+#endif
 #ifndef BP5_TIMING_BUILDS
   if (!product_variant(mf->degree, v)) return fail(BP5_ERR_INVALID, "unknown (degree, apply variant): timing-only builds live in libbp5_timing.so");
 #endif

@@ -567,6 +567,16 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
                      : launch_block_t<DEG, false, LPCB, 2048 + 8192 + 16384 + 262144 + HELM>(mf, coef, src, dst, overwrite);
       }
     }
+#ifdef BP5_TIMING_BUILDS
+    // timing-only ablations of the Helmholtz block kernel at p = 3 (wrong results; profiles/r4 j_*): 91 no write-out (and no combine pass), 93 no plane loads, 95 no gather
+    if constexpr (DEG == 3) if (mf->apply_variant == 91 || mf->apply_variant == 93 || mf->apply_variant == 95) {
+      if (!block_aligned(mf, c0, c1, &mf->blk_b0, &mf->blk_b1)) return fail(BP5_ERR_INVALID, "needs aligned cell blocks");
+      struct Reset { bp5_mf *m; ~Reset() { m->blk_b0 = m->blk_b1 = 0; } } reset{mf};
+      if (mf->apply_variant == 91) return launch_block_t<3, false, 16, 2048 + 8192 + 16384 + 262144 + HELM + 1>(mf, coef, src, dst, true);
+      if (mf->apply_variant == 93) return launch_block_t<3, false, 16, 2048 + 8192 + 16384 + 262144 + HELM + 2>(mf, coef, src, dst, true);
+      return launch_block_t<3, false, 16, 2048 + 8192 + 16384 + 262144 + HELM + 4>(mf, coef, src, dst, true);
+    }
+#endif
     if (mf->apply_variant != 0) return fail(BP5_ERR_UNSUPPORTED, "the Helmholtz operator runs apply variants 0 (pencil kernel) and 56 (block kernel)");
     if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
     if (c1 <= c0) return BP5_OK;

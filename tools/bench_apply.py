@@ -24,15 +24,17 @@ ap.add_argument("--numbering", type=int, default=0)
 ap.add_argument("--block-order", type=int, default=0, help="1: parity-class-major cell order inside a block")
 ap.add_argument("--geometry", choices=["merged6", "affine"], default="merged6")
 ap.add_argument("--overwrite", action="store_true", help="time vmult with zero_dst=1 instead of the accumulating cell loop")
+ap.add_argument("--operator", choices=["poisson", "helmholtz"], default="poisson", help="helmholtz: step-64's operator on the native fused kernel (seven planes)")
 a = ap.parse_args()
 p = a.degree
 mesh = pkg.BrickMesh(p, a.cells, h=1.0 / a.cells[0], deform_amp=a.deform, cell_block=a.cell_block, dof_numbering=a.numbering, cell_block_order=a.block_order)
 quad = pkg.QUAD_GAUSS if a.quadrature == "gauss" else pkg.QUAD_GLL
-op = pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE if a.geometry == 'affine' else pkg.GEOM_MERGED6)
+op = pkg.HelmholtzOperator(mesh, quad, pkg.COEF_STEP64) if a.operator == "helmholtz" else \
+    pkg.PoissonOperator(mesh, quad, pkg.COEF_STEP64, geometry=pkg.GEOM_AFFINE if a.geometry == 'affine' else pkg.GEOM_MERGED6)
 mf = op.mf_data
 n = mesh.n_owned
 r = mesh.n_cells * (p + 1) ** 3 / n
-B_op = 16 + 4 * r + (48 if a.geometry == 'merged6' else 8) * r
+B_op = 16 + 4 * r + ((56 if a.operator == 'helmholtz' else 48) if a.geometry == 'merged6' else 8) * r
 src = torch.rand(n, dtype=torch.float64, device="cuda") - 0.5
 dst = mf.initialize_dof_vector()
 times = {v: [] for v in a.variants}
