@@ -189,6 +189,9 @@ def main():
                     help="seconds the legs AFTER the timed region may take (sustained solves, unfused solve, exchange A/B, copy stream, traffic passes, CPU "
                          "baseline); then the line is printed with what is there and the process exits with code 4 (default: 600 at N = 1, 240 at N > 1) -- a hang in a "
                          "diagnostic leg of the first real multi-GPU run must not cost the measurement")
+    ap.add_argument("--control-backend", choices=["gloo", "nccl"], default="gloo",
+                    help="N > 1: torch.distributed backend of the bench's CONTROL plane (barriers, max over ranks of the wall clock, the id of the library's "
+                         "communicator); the data path is the library's own RCCL communicator either way")
     ap.add_argument("--no-exchange-ab", action="store_true",
                     help="N > 1: skip the diagnostic solves after the timed region (unsplit vs boundary-first exchange, phase stamps)")
     ap.add_argument("--rehearsal", action="store_true",
@@ -248,13 +251,21 @@ def main():
     if world > 1 and not args.dry_run:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # torch.distributed carries ONLY the bench's control plane (the barrier around the timed region, max / min over ranks of a float, the 128-byte
+        # id of the library's communicator).  The data path -- halo exchange and the per-iteration all-reduce -- is the library's own RCCL communicator.
+        # Default `--control-backend gloo`: then that communicator is the only RCCL communicator on the device (a second one, torch's, would meet it for
+        # the first time in the first real multi-GPU run), and it is the combination the N > 1 rehearsals of this repository have run; `nccl` on request.
+        control = "gloo" if args.rehearsal else args.control_backend
         try:
-            if args.rehearsal:
+            if control == "gloo":
+                if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container's hostname may not resolve
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             else:
                 dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         except Exception as e:   # noqa: BLE001
-            die("torch.distributed.init_process_group (rendezvous / RCCL bootstrap of torch's own communicator)", e)
+            die(f"torch.distributed.init_process_group (backend {control}: rendezvous / bootstrap of the bench's control plane)", e)
+        control_on_cpu = control == "gloo"
         try:
             comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
         except Exception as e:   # noqa: BLE001
@@ -313,7 +324,7 @@ def main():
         if world == 1:
             return v
         import torch.distributed as dist
-        tt = torch.tensor([float(v)], dtype=torch.float64, device="cpu" if args.rehearsal else f"cuda:{local_rank}")
+        tt = torch.tensor([float(v)], dtype=torch.float64, device="cpu" if control_on_cpu else f"cuda:{local_rank}")
         dist.all_reduce(tt, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[how])
         return float(tt.item())
 
@@ -414,6 +425,8 @@ def main():
                                    f"CG={args.variant} (identity preconditioner), G={G} I=1 ({args.geometry} geometry)",
                        "baseline_config": args.config if args.config else (3 if (p == 4 and base == HEADLINE_CELLS) else None),
                        "dofs_per_gpu": n_dofs_local, "parallelism": f"z-slab x{world} ({args.scaling} scaling)",
+                       "collectives": None if world == 1 else ("data path: the library's RCCL communicator (halo send/recv, one 7-double all-reduce per iteration); "
+                                                               f"bench control plane (barrier, max over ranks): torch.distributed over {'gloo' if (args.rehearsal or args.control_backend == 'gloo') else 'nccl'}"),
                        "cell_block": list(block) if blocked else None, "apply_variant": ev, "cg_dot_products_fused": fused,
                        "cg_dot_products_fused_on_every_rank": fused_all, "cg_dot_products_fused_on_some_rank": fused_any,
                        "exchange_schedule": SCHEDULES.get(ctl.exchange_schedule, "?"), "overlap_policy": args.overlap},

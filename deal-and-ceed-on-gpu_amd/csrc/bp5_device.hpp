@@ -321,7 +321,8 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     HIP_TRY(hipGetDeviceProperties(&prop, mf->device));
     mf->n_cus = prop.multiProcessorCount;
   }
-  const int wg_per_cu = ((ABL & 2048) && !(ABL & 8388608) && !BP5_ROLL_TWO(ABL) && lds * 3 <= 160 * 1024) ? 3 : lds * 2 <= 160 * 1024 ? 2 : 1; // (the Helmholtz build: two per CU, registers)
+  constexpr int wg_reg = block_wg_per_cu<P, ABL>(); // what the registers allow (launch bounds of the kernel) ...
+  const int wg_per_cu = std::max(1, std::min<int>(wg_reg, (int)(160 * 1024 / std::max<size_t>(lds, 1)))); // ... and what the LDS of this plan allows
   uint32_t n_wg = (uint32_t)(mf->n_cus * wg_per_cu);
   if (mf->block_max_wg > 0) n_wg = std::min<uint32_t>(n_wg, (uint32_t)mf->block_max_wg);
   n_wg = std::max<uint32_t>(8, std::min<uint32_t>(n_wg, (bp.n_blocks + 7) / 8 * 8) / 8 * 8);

@@ -1913,8 +1913,21 @@ struct BlockPass {
 // the rolling-prefetch builds (BlockPass::ROLL; libbp5_timing.so only) take 210-221 VGPRs: two workgroups per CU (capped at three waves per SIMD they spill
 // 100-150 registers and run at half the speed)
 #define BP5_ROLL_TWO(ABL) (((ABL) & 67108864) != 0)
+// workgroups per CU (= waves per SIMD: 256-thread workgroups) the block kernel is compiled for and launched with: three for the single-buffered builds
+// up to p = 4 (168 VGPRs), two otherwise (p >= 5: registers; Helmholtz; the rolling-prefetch probe).  p = 1 (round 4): FOUR -- the kernel needs 101 VGPRs
+// and 15 KB of LDS, and its waves wait two thirds of their life (profiles/r4 g_*): a pass is 64 cells with 6 loads per lane, all latency
+#ifndef BP5_WG_PER_CU_P1
+#define BP5_WG_PER_CU_P1 4
+#endif
+template <int P, int ABL>
+constexpr int block_wg_per_cu()
+{
+  if (!(ABL & 2048) || (ABL & 8388608) || BP5_ROLL_TWO(ABL) || P > 4) return 2;
+  if (P == 1 && !(ABL & 2097152) && !(ABL & 1024)) return BP5_WG_PER_CU_P1;
+  return 3;
+}
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
-__global__ void __launch_bounds__(256, ((ABL & 2048) && P <= 4 && !(ABL & 8388608) && !BP5_ROLL_TWO(ABL)) ? 3 : 2) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
+__global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
   using BP = BlockPass<P, COLL, LPC, SCATTER, ABL>;
   constexpr int n = P + 1, n2 = n * n;
