@@ -1277,6 +1277,9 @@ __device__ __forceinline__ unsigned long long stamp_now()
     tprev = now_;                                                                                                  \
   }
 
+#ifndef BP5_WAVE_PACK
+#define BP5_WAVE_PACK 1
+#endif
 template <int P, bool COLL, int LPC, int SCATTER, int ABL>
 struct BlockPass {
   static constexpr int n = P + 1, n2 = n * n, n3 = n2 * n;
@@ -1305,7 +1308,11 @@ struct BlockPass {
   static_assert(!ROLL || (((ABL & 2048) != 0) && ((ABL & 8192) != 0) && !AFFINE), "rolling prefetch: single-buffered build, sequential tiles, plane geometry");
   using R = PassRegs<n, AFFINE, NPL, ROLL>;
   // all lanes of a cell slot sit in one wave when LPC divides 64: the tile exchanges then need no block barrier
-  static constexpr bool WAVE_LOCAL = (64 % LPC == 0);
+  // WPACK (round 4, p = 2): 9 lanes per cell do not divide a wave, but SEVEN whole cells fit one (63 lanes) and 4 x 7 = 28 = 256 / 9 cells fill the pass
+  // all the same: with the cells packed wave by wave no cell spans two waves, every tile exchange is wave-local again (no workgroup barrier, no second
+  // tile) -- the kernel maps thread -> (cell slot, lane) accordingly (apply_block_kernel)
+  static constexpr bool WPACK = (BP5_WAVE_PACK != 0) && (64 % LPC != 0) && (4 * (64 / LPC) == TEAM / LPC);
+  static constexpr bool WAVE_LOCAL = (64 % LPC == 0) || WPACK;
   // SEQ: the transposes go through ONE field tile per cell, field after field (wave-local syncs are free), so a
   // workgroup needs a third of the tile memory: 4x4x4 accumulator + tiles = 47 KB -> three workgroups per CU
   static constexpr bool PACK = (ABL & 262144) != 0; // packed (run, offset) indices, decoded through the LDS run table
@@ -1919,11 +1926,15 @@ struct BlockPass {
 #ifndef BP5_WG_PER_CU_P1
 #define BP5_WG_PER_CU_P1 4
 #endif
+#ifndef BP5_WG_PER_CU_P2
+#define BP5_WG_PER_CU_P2 4
+#endif
 template <int P, int ABL>
 constexpr int block_wg_per_cu()
 {
   if (!(ABL & 2048) || (ABL & 8388608) || BP5_ROLL_TWO(ABL) || P > 4) return 2;
   if (P == 1 && !(ABL & 2097152) && !(ABL & 1024)) return BP5_WG_PER_CU_P1;
+  if (P == 2 && BP5_WAVE_PACK != 0 && !(ABL & 2097152) && !(ABL & 1024)) return BP5_WG_PER_CU_P2; // (wave-packed cells: one tile per slot, 36 KB of LDS on 8x8x4 bricks, 126 VGPRs)
   return 3;
 }
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
@@ -1938,7 +1949,10 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
   double *acc = lds + CPT * BP::TILE_CS; // accumulator behind the transpose tiles
 
   const int t = threadIdx.x;
-  const int c = t / LPC, ab = t - c * LPC;
+  // thread -> (cell slot c, lane ab of the cell): consecutive threads, or (BlockPass::WPACK) whole cells wave by wave, the wave's last lanes idle
+  constexpr int CW = 64 / LPC; // whole cells per wave
+  const int c = BP::WPACK ? (((t & 63) < CW * LPC) ? (t >> 6) * CW + (t & 63) / LPC : CPT) : t / LPC;
+  const int ab = BP::WPACK ? (t & 63) % LPC : t - c * LPC;
   // persistent workgroup w owns the contiguous block range [b0,b1); workgroups that share an XCD
   // (blockIdx % 8, speed only) own neighbouring ranges
   const uint32_t w = (blockIdx.x & 7u) * (bp.n_wg >> 3) + (blockIdx.x >> 3);
