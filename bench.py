@@ -149,6 +149,13 @@ def default_cell_block(p, cells_per_rank):
     return {1: (8, 8, 8), 2: (8, 8, 4), 3: (8, 4, 4), 4: (4, 4, 2) if small else (4, 4, 4), 5: (6, 4, 2), 6: (4, 4, 2), 7: (4, 2, 2), 8: (8, 8, 8)}.get(p, (0, 0, 0))
 
 
+def default_numbering(p, blocked):
+    """DoF numbering handed to the library (bp5_mesh_desc.dof_numbering; the operator accepts any): block-major with cell bricks (the deterministic block kernel's
+    lattice blocks).  `--numbering 2` (cell interiors first: the atomic pencil kernel of p >= 5 then stores them plainly) was measured at p = 8 in round 4 and buys
+    nothing there -- 1.130 against 1.125 ms, the kernel is bound by its arithmetic, not by the count of its atomics any more (profiles/r4 o_*)."""
+    return 1 if blocked else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +184,8 @@ def main():
     ap.add_argument("--cell-block", type=int, nargs=3, default=None,
                     help="hand the cells over in bricks of this many cells (default: 4 4 4 at p=4 -> block-assembled kernel, 8 8 8 at p>=5; "
                          "0 0 0 = lexicographic cell order -> pencil kernel with atomics)")
+    ap.add_argument("--numbering", type=int, choices=[0, 1, 2], default=None,
+                    help="bp5_mesh_desc.dof_numbering: 0 lexicographic, 1 block-major (needs cell bricks), 2 cell interiors first; default: 1 with bricks, 2 at p = 8")
     ap.add_argument("--sustained-iters", type=int, default=200, help="reference protocol: iterations per repetition (bp5/step-64.cu:729); 0 = skip")
     ap.add_argument("--sustained-reps", type=int, default=3, help="reference protocol: repetitions, best one reported (bp5/step-64.cu:457-463)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline leg")
@@ -289,7 +298,8 @@ def main():
         blk = tuple(block_) if block_ else default_cell_block(p_, cells_[0] * cells_[1] * cells_[2] // (world if strong else 1))
         blocked_ = all(b > 0 for b in blk)
         mesh_ = pkg.BrickMesh(p_, cells_, h=1.0 / cells_[0], deform_amp=args.deform, rank=rank, n_ranks=world,
-                              cell_block=blk if blocked_ else (0, 0, 0), dof_numbering=1 if blocked_ else 0, cell_block_order=1 if blocked_ else 0)
+                              cell_block=blk if blocked_ else (0, 0, 0), dof_numbering=default_numbering(p_, blocked_) if args.numbering is None else args.numbering,
+                              cell_block_order=1 if blocked_ else 0)
         return mesh_, blk, blocked_
 
     mesh, block, blocked = build(p, cells, args.cell_block)

@@ -73,6 +73,20 @@ extern "C" int bp5_mf_create(const bp5_mf_desc *d, bp5_mf **out)
     if (d->local_to_global_host[s] >= nloc) { return fail(BP5_ERR_INVALID, "local_to_global entry out of range"); }
   for (uint32_t s = 0; s < d->n_constrained; ++s)
     if (d->constrained_host[s] >= nloc) { return fail(BP5_ERR_INVALID, "constrained index out of range"); }
+  { // are the DoFs strictly inside a cell numbered ahead of all others, cell after cell, x fastest?  (bp5_mesh_desc.dof_numbering = 2, or any mesh numbered so)
+    const int p = d->degree, n = p + 1;
+    const uint32_t per = (uint32_t)((p - 1) * (p - 1) * (p - 1));
+    bool ok = p >= 2 && d->n_cells > 0 && (uint64_t)d->n_cells * per <= d->n_owned;
+    for (uint32_t c = 0; ok && c < d->n_cells; ++c) {
+      const uint32_t *l = d->local_to_global_host + (size_t)c * mf->n3;
+      uint32_t e = c * per;
+      for (int k = 1; ok && k < p; ++k)
+        for (int j = 1; j < p; ++j)
+          for (int i = 1; i < p; ++i, ++e)
+            if (l[i + n * (j + n * k)] != e) ok = false;
+    }
+    mf->cell_interiors_first = ok;
+  }
   mf->stream = (hipStream_t)d->stream; // NULL == the HIP default stream (ordered with the host's other default-stream work)
   BP5_TRY(upload(&mf->d_l2g, d->local_to_global_host, nl));
   mf->h_l2g.assign(d->local_to_global_host, d->local_to_global_host + nl);
@@ -1247,6 +1261,7 @@ static void tuning_from_environment(bp5_mf *mf)
   mf->tune[BP5_TUNE_UPDATE_FLAT] = env_int("BP5_UPDATE_FLAT", 1) != 0;
   { const int v = env_int("BP5_UPDATE_NT", -1); mf->tune[BP5_TUNE_UPDATE_NT] = v < 0 ? -1 : v != 0; }
   { const int v = env_int("BP5_COMBINE_WG_PER_CU", 16); mf->tune[BP5_TUNE_COMBINE_WG_PER_CU] = (v >= 0 && v <= 32) ? v : 16; }
+  mf->tune[BP5_TUNE_INTERIOR_STORES] = env_int("BP5_INTERIOR_STORES", 1) != 0;
 }
 extern "C" int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value)
 {

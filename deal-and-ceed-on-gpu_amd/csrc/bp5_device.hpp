@@ -105,7 +105,8 @@ struct bp5_mf {
   int wait_value_ok = -1;     // -1 not probed; 1: hipDeviceAttributeCanUseStreamWaitValue AND the producer / consumer self-check saw a mid-kernel release
   int can_wait_value = -1;    // wait_value_ok and not switched off by BP5_TUNE_BOUNDARY_FIRST = 0
   // per-handle tuning / A-B knobs (bp5.h: BP5_TUNE_*): initial values from the environment, read once by bp5_mf_create
-  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1, 16};
+  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1, 16, 1};
+  bool cell_interiors_first = false; // the mesh numbers the DoFs strictly inside a cell ahead of all others, cell after cell, x fastest (bp5_mesh_desc.dof_numbering = 2)
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
   int *d_st = nullptr;
@@ -668,6 +669,13 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
   // variants >= 100: the team kernel of (variant - 100) with the global-atomic scatter (A/B tests)
   mf->force_atomic_scatter = mf->apply_variant >= 100;
   int variant = mf->apply_variant % 100;
+  // cell-interior DoFs numbered ahead of all others (recognised by bp5_mf_create): the default pencil kernel of p >= 5 stores the entries a cell owns alone
+  // plainly -- (p-1)^3 of (p+1)^3 atomics less per cell (47 % at p = 8), and no store ever meets an atomic in one cache line
+  if constexpr (DEG >= 5) if (variant == 0 && !mf->force_atomic_scatter && mf->cell_interiors_first && mf->tune[BP5_TUNE_INTERIOR_STORES]) {
+    if (overwrite) HIP_TRY(hipMemsetAsync(dst, 0, mf->n_local() * sizeof(double), mf->stream));
+    return coll ? launch_apply_t<DEG, true, 4, (DEG + 1) * (DEG + 1), 1, true, 32>(mf, coef, src, dst, c0, c1)
+                : launch_apply_t<DEG, false, 4, (DEG + 1) * (DEG + 1), 1, true, 32>(mf, coef, src, dst, c0, c1);
+  }
   {
     APPLY_CASE(1, 0, 1, 4, 4, true);
     APPLY_CASE(1, 1, 1, 4, 4, true);

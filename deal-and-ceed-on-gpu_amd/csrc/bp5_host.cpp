@@ -459,7 +459,9 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   // ---- local DoF numbering of the owned range [0,NX) x [0,NY) x [Kown0,Ktop]
   const uint64_t zi0_ = z0 + (r > 0 ? 1 : 0);
   const bool blocked_ = d->cell_block[0] && d->cell_block[1] && d->cell_block[2];
+  if (d->dof_numbering < 0 || d->dof_numbering > 2) { delete m; return fail(BP5_ERR_INVALID, "dof_numbering must be 0, 1 or 2"); }
   if (d->dof_numbering == 1 && !blocked_) { delete m; return fail(BP5_ERR_INVALID, "block-major numbering needs cell_block"); }
+  const bool block_major = d->dof_numbering == 1 || (d->dof_numbering == 2 && blocked_); // (2: cell interiors first, the rest block-major where there are blocks)
   if (d->cell_block_order != 0 && (d->cell_block_order != 1 || !blocked_)) { delete m; return fail(BP5_ERR_INVALID, "cell_block_order must be 0, or 1 with cell_block"); }
   // per direction: slots are alternately block-boundary planes (length 1) and the runs between them
   struct Dir {
@@ -488,7 +490,7 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
     }
   };
   uint64_t class_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (d->dof_numbering == 1) {
+  if (block_major) {
     std::vector<uint64_t> px, py, pz;
     for (uint64_t X = 0; X < n0; X += d->cell_block[0]) px.push_back(p * X);
     px.push_back(p * n0);
@@ -514,7 +516,7 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   // then the lines between them, then their crossings -- every entity contiguous, x fastest -- so that the bricks of the ghost-touching
   // layer are lattice blocks like all others (bp5_device.hip: detect_lattice_blocks).  Sender and receiver use the same function.
   uint64_t plane_class_base[4] = {0, 0, 0, 0};
-  if (d->dof_numbering == 1) {
+  if (block_major) {
     uint64_t base2 = 0;
     for (int cl = 0; cl < 4; ++cl) { // (kx, ky) = (0,0), (1,0), (0,1), (1,1)
       plane_class_base[cl] = base2;
@@ -522,7 +524,7 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
     }
   }
   auto plane_pos = [&](uint64_t I, uint64_t J) -> uint64_t {
-    if (d->dof_numbering != 1) return I + NX * J;
+    if (!block_major) return I + NX * J;
     const uint64_t c2[2] = {I, J};
     int k[2]; uint64_t sl[2], in[2], Ls[2], Pr[2], Ss[2];
     for (int e = 0; e < 2; ++e) {
@@ -533,7 +535,7 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
   };
   auto local_of = [&](uint64_t I, uint64_t J, uint64_t K) -> uint32_t {
     if (K < Kown0) return (uint32_t)(n_owned + plane_pos(I, J)); // ghost plane K == Kbot, owned by rank-1
-    if (d->dof_numbering != 1) return (uint32_t)(I + NX * (J + NY * (K - Kown0)));
+    if (!block_major) return (uint32_t)(I + NX * (J + NY * (K - Kown0)));
     const uint64_t c3[3] = {I, J, K - Kown0};
     int k[3]; uint64_t sl[3], in[3], Ls[3], Pr[3], Ss[3];
     for (int e = 0; e < 3; ++e) {
@@ -628,6 +630,36 @@ extern "C" int bp5_mesh_create_brick(const bp5_mesh_desc *d, bp5_mesh **out)
     m->send_indices.insert(m->send_indices.end(), by_pos.begin(), by_pos.end());
     m->send_offsets.push_back((uint32_t)m->send_indices.size());
     m->recv_offsets.push_back(m->recv_offsets.back());
+  }
+  // dof_numbering = 2: the owned DoFs strictly inside a cell first, cell after cell in the order the cells are handed over ((p - 1)^3 consecutive
+  // DoFs per cell, x fastest), then all other owned DoFs in the order of numbering 0 (or 1 with cell_block); ghosts keep their places.  A renumbering
+  // of the finished mesh: every array that names a local DoF is mapped through it.
+  if (d->dof_numbering == 2 && p >= 2) {
+    std::vector<uint32_t> newid(n_owned, 0xffffffffu);
+    uint32_t next = 0;
+    for (size_t cc = 0; cc < n_cells; ++cc)
+      for (int k = 1; k < p; ++k)
+        for (int j = 1; j < p; ++j)
+          for (int i = 1; i < p; ++i) {
+            const uint32_t old = m->l2g[cc * nl + i + n * (j + n * k)];
+            if (old < n_owned) newid[old] = next++; // (always: only the bottom PLANE of a rank's cells is ghost)
+          }
+    for (uint64_t o = 0; o < n_owned; ++o)
+      if (newid[o] == 0xffffffffu) newid[o] = next++;
+    auto map = [&](uint32_t o) -> uint32_t { return o < n_owned ? newid[o] : o; };
+    for (uint32_t &v : m->l2g) v = map(v);
+    for (uint32_t &v : m->constrained) v = map(v);
+    std::sort(m->constrained.begin(), m->constrained.end());
+    for (uint32_t &v : m->send_indices) v = map(v);
+    std::vector<double> co(m->coords.size());
+    std::vector<uint64_t> gi(m->gids.size());
+    for (uint64_t o = 0; o < nloc; ++o) {
+      const uint32_t q = map((uint32_t)o);
+      for (int e = 0; e < 3; ++e) co[3 * (size_t)q + e] = m->coords[3 * (size_t)o + e];
+      gi[q] = m->gids[o];
+    }
+    m->coords.swap(co);
+    m->gids.swap(gi);
   }
   *out = m;
   return BP5_OK;

@@ -575,6 +575,19 @@ __global__ void __launch_bounds__(64 * TW * TPB, (ABL & 512) ? (TW * TPB) : 1) a
         else a.dst[cell * n3 + k * n2 + abm] = y[k];
       }
     }
+  } else if constexpr ((ABL & 32) != 0) {
+    // Cell-interior entries (1 <= i, j, k <= n - 2: (n - 2)^3 of n^3, 47 % at p = 8) belong to this cell alone: a plain store instead of a memory-side
+    // atomic -- the kernel is bound by the COUNT of its atomics.  Correct on any mesh; it pays only where these DoFs do not share cache
+    // lines with atomically updated ones ("an atomic to a line that is dirty in L2 forces its write-back": stores mixed into such lines cost 21 % at p = 4),
+    // i.e. with the cell-interior DoFs numbered contiguously ahead of all others (bp5_mesh_desc.dof_numbering = 2; bp5_mf_create detects the property)
+    if (active) {
+      const bool lane_interior = a_ >= 1 && a_ <= n - 2 && b_ >= 1 && b_ <= n - 2;
+#pragma unroll
+      for (int k = 0; k < n; ++k) {
+        if (lane_interior && k >= 1 && k <= n - 2) a.dst[idx[k]] = y[k];
+        else atomic_add_f64(a.dst + idx[k], y[k]);
+      }
+    }
   } else if (active) {
 #pragma unroll
     for (int k = 0; k < n; ++k) atomic_add_f64(a.dst + idx[k], y[k]);

@@ -79,7 +79,12 @@ typedef struct {
                           1: block-major (needs cell_block): the DoFs strictly inside a cell block are
                              numbered contiguously, then block faces, edges, vertices -- every entity
                              contiguous.  A brick's gather/scatter then touches a few long runs instead
-                             of many short rows.  global_ids_host always gives the lexicographic id. */
+                             of many short rows.  global_ids_host always gives the lexicographic id.
+                          2: the owned DoFs strictly INSIDE a cell first, cell after cell in the order the cells are handed over
+                             ((p-1)^3 consecutive DoFs per cell, x fastest), then all other owned DoFs as in 0 (as in 1 where
+                             cell_block is given).  bp5_mf_create recognises this property of a mesh (whoever numbered it) and the
+                             pencil kernel of p >= 5 then stores cell-interior entries plainly instead of adding them atomically:
+                             they share no cache line with an atomically updated DoF (half the atomics at p = 8). */
   int cell_block_order; /* order of the cells inside a block: 0 lexicographic (x fastest); 1 parity class by
                              parity class ((x&1, y&1, z&1) relative to the block corner, lexicographic inside a
                              class): consecutive cells then share no DoF, which is the order the block-assembled
@@ -281,10 +286,12 @@ int bp5_mf_set_streaming(bp5_mf *mf, int policy);
  *                              -1 = the library's default (on at every size: -0.9 % per iteration at 1e8 DoFs, -1.2 % at 1e7).
  *   BP5_TUNE_COMBINE_WG_PER_CU (env BP5_COMBINE_WG_PER_CU, 0 ... 32, default 16) workgroups per CU of the fused solver's combine pass (a fixed grid that walks
  *                              the tiles of brick-surface DoFs, one dot-product column per workgroup); 0 = as many workgroups as columns are free
- *                              (rounds 2-3).  The dot products are summed over another column layout (rounding-level differences), v is the same bits. */
+ *                              (rounds 2-3).  The dot products are summed over another column layout (rounding-level differences), v is the same bits.
+ *   BP5_TUNE_INTERIOR_STORES   (env BP5_INTERIOR_STORES, default 1) atomic pencil kernel of p >= 5 on a mesh whose cell-interior DoFs are numbered ahead of all
+ *                              others (bp5_mesh_desc.dof_numbering = 2; detected at bp5_mf_create): plain stores for the (p-1)^3 entries a cell owns alone. */
 enum { BP5_TUNE_LATTICE_INDICES = 0, BP5_TUNE_EARLY_GATHER = 1, BP5_TUNE_COMBINE_SIGNAL = 2, BP5_TUNE_BOUNDARY_FIRST = 3,
        BP5_TUNE_FOLD_SMALL = 4, BP5_TUNE_UPDATE_UNROLL = 5, BP5_TUNE_UPDATE_FLAT = 6, BP5_TUNE_UPDATE_NT = 7, BP5_TUNE_COMBINE_WG_PER_CU = 8,
-       BP5_TUNE_COUNT = 9 };
+       BP5_TUNE_INTERIOR_STORES = 9, BP5_TUNE_COUNT = 10 };
 int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value);
 int bp5_mf_get_tuning(const bp5_mf *mf, int knob, int *value);
 /* 1 when the in-launch stream wait-value schedules are available on this handle (capability + self-check, see BP5_TUNE_BOUNDARY_FIRST);

@@ -218,6 +218,30 @@ def test_bench_launches_its_own_ranks_and_strong_scales_by_default():
         assert parts[0]["neighbors"] == [1] and parts[1]["neighbors"] == [0] and parts[1]["n_ghost"] == 33 * 33
 
 
+@pytest.mark.parametrize("p,cells,block,kw", [(8, (3, 3, 2), (0, 0, 0), {}), (5, (4, 3, 5), (2, 2, 2), dict(rank=1, n_ranks=2)), (3, (4, 3, 3), (0, 0, 0), {}),
+                                            (2, (3, 3, 3), (2, 2, 2), dict(rank=0, n_ranks=2)), (4, (5, 4, 6), (4, 4, 2), dict(rank=2, n_ranks=3))])
+def test_mesh_numbering_cell_interiors_first(p, cells, block, kw):
+    """bp5_mesh_desc.dof_numbering = 2 (round 4): the owned DoFs strictly inside a cell come first, (p-1)^3 consecutive DoFs per cell in the order the cells are handed
+    over; everything else is the same mesh: the same global DoFs per cell entry, the same Dirichlet set, coordinates, ghosts and halo plan as the numbering it renumbers."""
+    blocked = all(b > 0 for b in block)
+    m2 = pkg.BrickMesh(p, cells, h=0.25, deform_amp=0.03, cell_block=block, dof_numbering=2, cell_block_order=1 if blocked else 0, **kw)
+    m1 = pkg.BrickMesh(p, cells, h=0.25, deform_amp=0.03, cell_block=block, dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0, **kw)
+    per = (p - 1) ** 3
+    inner = np.asarray(m2.l2g).reshape(m2.n_cells, p + 1, p + 1, p + 1)[:, 1:p, 1:p, 1:p].reshape(m2.n_cells, per)
+    assert np.array_equal(inner, np.arange(m2.n_cells * per).reshape(m2.n_cells, per))
+    g1, g2 = np.asarray(m1.global_ids).astype(np.int64), np.asarray(m2.global_ids).astype(np.int64)
+    assert (m1.n_owned, m1.n_ghost, m1.n_cells, m1.n_interior_cells) == (m2.n_owned, m2.n_ghost, m2.n_cells, m2.n_interior_cells)
+    assert np.array_equal(g1[np.asarray(m1.l2g).astype(np.int64)], g2[np.asarray(m2.l2g).astype(np.int64)])
+    assert np.array_equal(np.sort(g1[:m1.n_owned]), np.sort(g2[:m2.n_owned])) and np.array_equal(g1[m1.n_owned:], g2[m2.n_owned:])
+    assert np.array_equal(np.sort(g1[np.asarray(m1.constrained).astype(np.int64)]), np.sort(g2[np.asarray(m2.constrained).astype(np.int64)]))
+    assert np.all(np.diff(np.asarray(m2.constrained).astype(np.int64)) > 0)
+    c1, c2 = np.asarray(m1.coords).reshape(-1, 3), np.asarray(m2.coords).reshape(-1, 3)
+    assert np.array_equal(c1[np.argsort(g1)], c2[np.argsort(g2)])
+    assert np.array_equal(g1[np.asarray(m1.send_indices).astype(np.int64)], g2[np.asarray(m2.send_indices).astype(np.int64)])
+    with pytest.raises(pkg.BP5Error):
+        pkg.BrickMesh(p, cells, dof_numbering=3)
+
+
 def test_bench_default_mesh_splits_into_equal_slabs_at_2_4_8_ranks():
     """BASELINE config 3 under strong scaling: the default mesh has 120 cell layers, so that 2, 4 and 8 z-slabs hold the same number of
     cells (116 layers gave one of eight ranks 15 against a mean of 14.5: +3.4 %); owned DoFs differ only by the interface plane the lower rank owns (< 2 %).

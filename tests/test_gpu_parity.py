@@ -1252,6 +1252,53 @@ def test_single_rank_communicator_and_distributed_entry_points():
     comm.close()
 
 
+@pytest.mark.parametrize("p,cells,block,kw", [(8, (3, 3, 2), (0, 0, 0), {}), (8, (4, 4, 4), (2, 2, 2), {}), (5, (4, 3, 5), (2, 2, 2), dict(rank=1, n_ranks=2)),
+                                            (6, (3, 4, 3), (0, 0, 0), {}), (7, (3, 2, 3), (2, 2, 2), {}), (3, (4, 3, 3), (0, 0, 0), {})])
+def test_cell_interior_dofs_numbered_first_are_stored_plainly(p, cells, block, kw):
+    """bp5_mesh_desc.dof_numbering = 2 (round 4): the DoFs strictly inside a cell come first, cell after cell.  bp5_mf_create recognises the property and the default
+    pencil kernel of p >= 5 stores the (p-1)^3 entries a cell owns alone with plain stores instead of memory-side atomics (kernel id 32: half the atomics at p = 8,
+    none of them in a cache line a store touches).  The cell loop of every rank's slab summed through the global ids against the oracle's, the merged solve against
+    the oracle's; the knob switches the build off; the same mesh numbered otherwise never takes it."""
+    torch = _t()
+    blocked = all(b > 0 for b in block)
+    n_ranks = kw.get("n_ranks", 1)
+    pr = O.Problem(p, cells, 0, deform_amp=0.03, kappa=O.kappa_step64, h=0.25)
+    s = O.deterministic_src(pr.mesh.n_dofs, seed=3)
+    ref = O.apply_cells(pr.mesh, pr.coef, pr.N, pr.D, s)            # cell loop: no Dirichlet copy
+    per = (p - 1) ** 3
+    total = np.zeros(pr.mesh.n_dofs)
+    for r in range(n_ranks):
+        mesh = pkg.BrickMesh(p, cells, h=0.25, deform_amp=0.03, cell_block=block, dof_numbering=2, cell_block_order=1 if blocked else 0, rank=r, n_ranks=n_ranks)
+        inner = np.asarray(mesh.l2g).reshape(mesh.n_cells, p + 1, p + 1, p + 1)[:, 1:p, 1:p, 1:p].reshape(mesh.n_cells, per)
+        assert np.array_equal(inner, np.arange(mesh.n_cells * per, dtype=np.int64).reshape(mesh.n_cells, per))     # cell after cell, x fastest
+        gid = np.asarray(mesh.global_ids).astype(np.int64)
+        op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+        d = op.initialize_dof_vector()
+        op.mf_data.cell_loop(op.coef, dev(s[gid]), d)
+        np.add.at(total, gid, d.cpu().numpy())                       # owned and ghost entries land on their global ids
+    assert rel(total, ref) < TOL_OP
+    if n_ranks == 1:
+        no = mesh.n_owned
+        ctl = pkg.IterationNumberControl(3, 0.0)
+        x = op.initialize_dof_vector()
+        pkg.SolverCGFullMerge(ctl).solve(op, x, op.assemble_rhs(), pkg.DiagonalMatrix())
+        xr, _, _ = O.cg_merged(pr.vmult, pr.rhs(), 3)
+        assert rel(x.cpu().numpy(), xr[gid[:no]]) < 1e-10
+        assert (ctl.apply_kernel.startswith("apply_pencil_kernel") and ctl.apply_kernel.endswith(",32>")) == (p >= 5), ctl.apply_kernel   # (p = 3: the team kernel)
+        op.mf_data.set_tuning("interior_stores", 0)
+        c0 = pkg.IterationNumberControl(3, 0.0)
+        x0 = op.initialize_dof_vector()
+        pkg.SolverCGFullMerge(c0).solve(op, x0, op.assemble_rhs(), pkg.DiagonalMatrix())
+        assert not c0.apply_kernel.endswith(",32>") and rel(x0.cpu().numpy(), xr[gid[:no]]) < 1e-10
+        # the same mesh numbered block-major / lexicographically is not recognised
+        mesh1 = pkg.BrickMesh(p, cells, h=0.25, deform_amp=0.03, cell_block=block, dof_numbering=1 if blocked else 0, cell_block_order=1 if blocked else 0)
+        op1 = pkg.PoissonOperator(mesh1, 0, pkg.COEF_STEP64)
+        op1.mf_data.set_apply_variant(0)
+        c1 = pkg.IterationNumberControl(2, 0.0)
+        pkg.SolverCGFullMerge(c1).solve(op1, op1.initialize_dof_vector(), op1.assemble_rhs(), pkg.DiagonalMatrix())
+        assert not c1.apply_kernel.endswith(",32>"), c1.apply_kernel
+
+
 @pytest.mark.parametrize("p,cells,seed", [(2, (4, 3, 3), 1), (4, (4, 3, 2), 2), (5, (3, 2, 2), 3)])
 def test_externally_numbered_mesh(p, cells, seed):
     """nothing in the library assumes the structured generator.  The flat arrays of bp5_mf_desc come
