@@ -37,7 +37,7 @@
 #include <vector>
 
 namespace {
-constexpr int MAX_RANKS = 4, SLOTS = 4, MAX_REDUCE = 1024, RING = 16;
+constexpr int MAX_RANKS = 6, SLOTS = 4, MAX_REDUCE = 1024, RING = 16;
 constexpr size_t SLOT_BYTES = size_t(4) << 20;
 constexpr double TIMEOUT_S = 120.0;
 

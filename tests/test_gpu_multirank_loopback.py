@@ -85,6 +85,9 @@ def _stop_tolerance(pr, k_min=8, k_max=40):
     (4, 4, (4, 4, 9), (4, 4, 2), 1, 56, 0),   # four ranks: two middle ranks, slabs of 3 / 2 / 2 / 2 layers (thinner than a brick)
     (3, 3, (5, 4, 7), (2, 2, 2), 1, 10, 0),   # team kernel (LDS-staged atomics) behind the exchange
     (2, 1, (6, 5, 6), (0, 0, 0), 0, 0, 0),    # p = 1
+    (5, 4, (4, 4, 10), (4, 4, 2), 1, 56, 0),  # five ranks (the most this box lets one test run beside its own process): three middle ranks, equal slabs of one brick layer
+    (2, 2, (8, 8, 8), (8, 8, 4), 1, 56, 0),   # p = 2 on the block kernel with its cells packed wave by wave (round 4), one brick layer per rank
+    (2, 1, (8, 8, 16), (8, 8, 8), 1, 56, 0),  # p = 1 on the block kernel at four workgroups per CU (round 4)
 ])
 def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells, block, numbering, variant, delay_us):
     iters = 8
