@@ -7,9 +7,9 @@ tag=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/stats -o s --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic-pass --sustained-iters 0 > $R/gpurun_out/$tag/bench_stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/stats -o s --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic-pass --no-mesh-116 --sustained-iters 0 > $R/gpurun_out/$tag/bench_stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/$tag/pmc_$c -o p --output-format csv -- python3 $R/bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-traffic-pass --sustained-iters 0 > $R/gpurun_out/$tag/bench_pmc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/$tag/pmc_$c -o p --output-format csv -- python3 $R/bench.py --gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --no-traffic-pass --no-mesh-116 --sustained-iters 0 > $R/gpurun_out/$tag/bench_pmc_$c.log 2>&1
 done
 cd $R
 python3 - "$tag" <<'PY'

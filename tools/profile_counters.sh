@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/$tag/g$i -o p --output-format csv -- python3 $R/bench.py --gpus 1 $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-pass --sustained-iters 0 > $R/gpurun_out/$tag/g$i.log 2>&1 || echo "group $i failed: $grp"
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/$tag/g$i -o p --output-format csv -- python3 $R/bench.py --gpus 1 $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-pass --no-mesh-116 --sustained-iters 0 > $R/gpurun_out/$tag/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 cd $R
 python3 - "$tag" <<'PY'
