@@ -479,7 +479,9 @@ def main():
                          "operator_kernel_unfused": ({"avg_launch_ms": unfused_ms, "bytes_per_dof": B_op,
                                                       "frac": B_op * n_dofs_local / (unfused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if unfused_ms else None),
                          "algorithmic_formula": (f"16 + I*4r + G*8r" + (" + 24 [fused dot products: p, r, v]" if fused else "") +
-                                                 f" B/DoF with I=1, G={G}, r={r:.4f} (SURVEY 8d)"),
+                                                 f" B/DoF with I=1 (contract)" + ("; the kernel itself reads one u32 per CELL" if lattice_kernel else
+                                                                                  "; the kernel itself reads one packed u16 per local DoF" if block_kernel else "") +
+                                                 f", G={G}, r={r:.4f} (SURVEY 8d)"),
                          # what this kernel has to move for its own representation (the contract formula credits I = 1 and 24 B for the dots)
                          "bytes_moved_formula": ((("16 + 4r/(p+1)^3 + G*8r" if lattice_kernel else "16 + 2r + G*8r") +
                                                   (" + 8 [r at the stored DoFs; p.v comes from the quadrature-point energy, v.v from LDS]" if fused else "") +
