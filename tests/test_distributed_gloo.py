@@ -215,7 +215,9 @@ def _worker(rank, world, port, p, cells, quad, amp, numbering, block, iters, out
 
 @pytest.mark.parametrize("world,p,cells,numbering,block", [(2, 2, (3, 3, 4), 0, (0, 0, 0)), (2, 3, (4, 3, 5), 1, (2, 2, 2)),
                                                            (3, 1, (3, 2, 7), 0, (2, 2, 2)),
-                                                           (2, 4, (5, 4, 6), 1, (4, 4, 4))])   # the bench's ordering (parity-class bricks)
+                                                           (2, 4, (5, 4, 6), 1, (4, 4, 4)),    # the bench's ordering (parity-class bricks)
+                                                           (8, 4, (4, 4, 16), 1, (4, 4, 2)),   # EIGHT ranks, equal slabs of one brick layer: first, six middle, last rank (BASELINE config 3's split)
+                                                           (8, 2, (3, 3, 11), 0, (0, 0, 0))])  # eight ranks, ragged slabs (1 or 2 cell layers)
 def test_distributed_cg_matches_single_domain(tmp_path, world, p, cells, numbering, block):
     quad, amp, iters = O.QUAD_GAUSS, 0.03, 8
     port = _free_port()
