@@ -266,16 +266,24 @@ def main():
         # Default `--control-backend gloo`: then that communicator is the only RCCL communicator on the device (a second one, torch's, would meet it for
         # the first time in the first real multi-GPU run), and it is the combination the N > 1 rehearsals of this repository have run; `nccl` on request.
         control = "gloo" if args.rehearsal else args.control_backend
-        try:
-            if control == "gloo":
-                if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
-                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container's hostname may not resolve
+        if control == "gloo":
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container's hostname may not resolve
+            try:
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            else:
+            except Exception as e:   # noqa: BLE001
+                # (every rank of one node fails here alike -- no interface, no rendezvous --, so all of them fall back together)
+                sys.stderr.write(f"[bench rank {rank}/{world}] gloo control plane unavailable ({type(e).__name__}: {e}); falling back to nccl\n")
+                if args.rehearsal:
+                    die("torch.distributed.init_process_group (backend gloo)", e)
+                control = "nccl"
+        if control == "nccl":
+            try:
                 dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        except Exception as e:   # noqa: BLE001
-            die(f"torch.distributed.init_process_group (backend {control}: rendezvous / bootstrap of the bench's control plane)", e)
+            except Exception as e:   # noqa: BLE001
+                die("torch.distributed.init_process_group (backend nccl: rendezvous / RCCL bootstrap of the bench's control plane)", e)
         control_on_cpu = control == "gloo"
+        args.control_backend = control
         try:
             comm = pkg.Communicator.from_torch_distributed()   # library-side RCCL communicator (id broadcast through torch)
         except Exception as e:   # noqa: BLE001
