@@ -1262,6 +1262,7 @@ static void tuning_from_environment(bp5_mf *mf)
   { const int v = env_int("BP5_UPDATE_NT", -1); mf->tune[BP5_TUNE_UPDATE_NT] = v < 0 ? -1 : v != 0; }
   { const int v = env_int("BP5_COMBINE_WG_PER_CU", 16); mf->tune[BP5_TUNE_COMBINE_WG_PER_CU] = (v >= 0 && v <= 32) ? v : 16; }
   mf->tune[BP5_TUNE_INTERIOR_STORES] = env_int("BP5_INTERIOR_STORES", 1) != 0;
+  mf->tune[BP5_TUNE_GHOST_COMBINE_ON_COMM] = env_int("BP5_GHOST_COMBINE_ON_COMM", 0) != 0;
 }
 extern "C" int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value)
 {
@@ -1639,6 +1640,19 @@ static int solver_vmult(bp5_mf *mf, const double *coef, double *src, double *dst
         if (st == BP5_OK && hipStreamWaitValue64(mf->comm_stream, mf->d_signal, mf->signal_target, hipStreamWaitValueGte, ~0ull) != hipSuccess)
           st = fail(BP5_ERR_HIP, "hipStreamWaitValue64");
         if (st == BP5_OK) st = scatter_exchange(mf, dst, true, true);
+      } else if (mf->tune[BP5_TUNE_GHOST_COMBINE_ON_COMM] && mf->n_ghost) {
+        // the ghost rows of the combine pass on the COMMUNICATION stream (behind an event that says the brick kernel is done, in front of the send): the
+        // owned rows start right behind the brick kernel on the compute stream -- one small launch and its gap off the critical path (same kernels, same bits)
+        if (st == BP5_OK && hipEventRecord(mf->ev_halo[2], mf->stream) != hipSuccess) st = fail(BP5_ERR_HIP, "hipEventRecord");
+        if (st == BP5_OK && hipStreamWaitEvent(mf->comm_stream, mf->ev_halo[2], 0) != hipSuccess) st = fail(BP5_ERR_HIP, "hipStreamWaitEvent");
+        if (st == BP5_OK) {
+          hipStream_t compute = mf->stream;
+          mf->stream = mf->comm_stream;
+          st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
+          mf->stream = compute;
+        }
+        if (st == BP5_OK) st = scatter_exchange(mf, dst, true, true);
+        if (st == BP5_OK) st = launch_combine(mf, dp, dst, true, COMBINE_OWNED);
       } else {
         if (st == BP5_OK && mf->n_ghost) st = launch_combine(mf, dp, dst, true, COMBINE_GHOST);
         if (st == BP5_OK) st = scatter_exchange(mf, dst, true);

@@ -105,7 +105,7 @@ struct bp5_mf {
   int wait_value_ok = -1;     // -1 not probed; 1: hipDeviceAttributeCanUseStreamWaitValue AND the producer / consumer self-check saw a mid-kernel release
   int can_wait_value = -1;    // wait_value_ok and not switched off by BP5_TUNE_BOUNDARY_FIRST = 0
   // per-handle tuning / A-B knobs (bp5.h: BP5_TUNE_*): initial values from the environment, read once by bp5_mf_create
-  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1, 16, 1};
+  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1, 16, 1, 0};
   bool cell_interiors_first = false; // the mesh numbers the DoFs strictly inside a cell ahead of all others, cell after cell, x fastest (bp5_mesh_desc.dof_numbering = 2)
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;

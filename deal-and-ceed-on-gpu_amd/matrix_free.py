@@ -160,7 +160,7 @@ class MatrixFree:
         _lib.check(_lib.lib().bp5_mf_set_streaming(self.handle, int(policy)))
 
     TUNE = {"lattice_indices": 0, "early_gather": 1, "combine_signal": 2, "boundary_first": 3, "fold_small": 4, "update_unroll": 5,
-            "update_flat": 6, "update_nt": 7, "combine_wg_per_cu": 8, "interior_stores": 9}   # bp5.h: BP5_TUNE_*
+            "update_flat": 6, "update_nt": 7, "combine_wg_per_cu": 8, "interior_stores": 9, "ghost_combine_on_comm": 10}   # bp5.h: BP5_TUNE_*
 
     def set_tuning(self, knob, value):
         """Per-handle A/B knob (bp5.h BP5_TUNE_*; same bits for every setting); knob by name or number."""

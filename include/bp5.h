@@ -287,11 +287,13 @@ int bp5_mf_set_streaming(bp5_mf *mf, int policy);
  *   BP5_TUNE_COMBINE_WG_PER_CU (env BP5_COMBINE_WG_PER_CU, 0 ... 32, default 16) workgroups per CU of the fused solver's combine pass (a fixed grid that walks
  *                              the tiles of brick-surface DoFs, one dot-product column per workgroup); 0 = as many workgroups as columns are free
  *                              (rounds 2-3).  The dot products are summed over another column layout (rounding-level differences), v is the same bits.
+ *   BP5_TUNE_GHOST_COMBINE_ON_COMM (env BP5_GHOST_COMBINE_ON_COMM, default 0) default exchange schedule (overlap 2): the ghost-row window of the combine pass on the
+ *                              communication stream (in front of the send) instead of the compute stream, so that the owned-row window starts right behind the brick kernel.
  *   BP5_TUNE_INTERIOR_STORES   (env BP5_INTERIOR_STORES, default 1) atomic pencil kernel of p >= 5 on a mesh whose cell-interior DoFs are numbered ahead of all
  *                              others (bp5_mesh_desc.dof_numbering = 2; detected at bp5_mf_create): plain stores for the (p-1)^3 entries a cell owns alone. */
 enum { BP5_TUNE_LATTICE_INDICES = 0, BP5_TUNE_EARLY_GATHER = 1, BP5_TUNE_COMBINE_SIGNAL = 2, BP5_TUNE_BOUNDARY_FIRST = 3,
        BP5_TUNE_FOLD_SMALL = 4, BP5_TUNE_UPDATE_UNROLL = 5, BP5_TUNE_UPDATE_FLAT = 6, BP5_TUNE_UPDATE_NT = 7, BP5_TUNE_COMBINE_WG_PER_CU = 8,
-       BP5_TUNE_INTERIOR_STORES = 9, BP5_TUNE_COUNT = 10 };
+       BP5_TUNE_INTERIOR_STORES = 9, BP5_TUNE_GHOST_COMBINE_ON_COMM = 10, BP5_TUNE_COUNT = 11 };
 int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value);
 int bp5_mf_get_tuning(const bp5_mf *mf, int knob, int *value);
 /* 1 when the in-launch stream wait-value schedules are available on this handle (capability + self-check, see BP5_TUNE_BOUNDARY_FIRST);

@@ -86,6 +86,9 @@ def main():
         op.mf_data.set_tuning("combine_signal", 1)  # the default schedule with ONE combine launch (ghost rows first, stream wait-value): the same bits
         solve(pkg.SolverCGFullMerge, 2, True, "merged_default_one_combine_launch")
         op.mf_data.set_tuning("combine_signal", 0)
+        op.mf_data.set_tuning("ghost_combine_on_comm", 1)   # the default schedule with the ghost-row combine on the communication stream (round 4): the same bits
+        solve(pkg.SolverCGFullMerge, 2, True, "merged_default_ghost_combine_on_comm")
+        op.mf_data.set_tuning("ghost_combine_on_comm", 0)
         res["norms"] = np.asarray(norms)
         if stop_tol > 0.0:
             # tolerance stop across ranks: every rank sees the same all-reduced residual, the device-side convergence flag fires on all of them in

@@ -116,7 +116,7 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
     x_merged, _, res_merged = O.cg_merged(pr.vmult, b_ref, iters)
     assert _rel(full["x_plain"], x_plain) < 1e-11 and _rel(full["x_plain_overlapped"], x_plain) < 1e-11
     merged = ["merged_unsplit", "merged_overlapped", "merged_default", "merged_unfused", "merged_unsplit_again", "merged_overlapped_again",
-              "merged_unsplit_late_gather", "merged_overlapped_late_gather", "merged_default_one_combine_launch"]
+              "merged_unsplit_late_gather", "merged_overlapped_late_gather", "merged_default_one_combine_launch", "merged_default_ghost_combine_on_comm"]
     for k in merged:
         assert _rel(full["x_" + k], x_merged) < 1e-11, k
     on_block_kernel = int(ranks[0]["variant"]) == 56
@@ -132,6 +132,7 @@ def test_ranks_on_one_gpu_match_the_undivided_problem(tmp_path, world, p, cells,
         assert np.array_equal(full["x_merged_overlapped_late_gather"], full["x_merged_unsplit"])
         # BP5_COMBINE_SIGNAL=1: ghost rows and owned rows of the combine pass in ONE launch, the exchange released by a stream wait-value
         assert np.array_equal(full["x_merged_default_one_combine_launch"], full["x_merged_unsplit"])
+        assert np.array_equal(full["x_merged_default_ghost_combine_on_comm"], full["x_merged_unsplit"])   # ghost-row combine on the communication stream
     # tolerance stop across the ranks: the same iteration as the oracle on the undivided mesh, on every rank, in every schedule; iterate frozen there
     x_stop, k_ref, _ = O.cg_plain(pr1.vmult, pr1.rhs(), 400, tol=stop_tol)
     assert k_ref == k_stop
