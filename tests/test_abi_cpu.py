@@ -242,6 +242,19 @@ def test_mesh_numbering_cell_interiors_first(p, cells, block, kw):
         pkg.BrickMesh(p, cells, dof_numbering=3)
 
 
+@pytest.mark.parametrize("probe", ["hbm_sweep", "metric_stream", "wait_value_probe"])
+def test_probes_compile_for_gfx950(tmp_path, probe):
+    """tools/probes/*.hip (the standalone measurements profiles/r3, r4 quote) cross-compile for gfx950: they stay runnable as the toolchain moves."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(bp5_pkg.ROOT, "tools", "probes", probe + ".hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-c", src, "-o", str(tmp_path / (probe + ".o"))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_bench_default_mesh_splits_into_equal_slabs_at_2_4_8_ranks():
     """BASELINE config 3 under strong scaling: the default mesh has 120 cell layers, so that 2, 4 and 8 z-slabs hold the same number of
     cells (116 layers gave one of eight ranks 15 against a mean of 14.5: +3.4 %); owned DoFs differ only by the interface plane the lower rank owns (< 2 %).
