@@ -161,6 +161,7 @@ def lib():
         "bp5_mf_set_cg_fusion": (i32, [vp, i32]),
         "bp5_mf_set_operator": (i32, [vp, i32]),
         "bp5_mf_block_plan_lattice": (i32, [vp, vp]),
+        "bp5_mf_block_plan_carry": (i32, [vp, vp, vp, vp]),
         "bp5_halo_scatter_add": (i32, [vp, vp]),
         "bp5_halo_zero_ghosts": (i32, [vp, vp]),
         "bp5_apply_distributed": (i32, [vp, vp, vp, vp, i32]),

@@ -199,6 +199,10 @@ extern "C" int bp5_mf_destroy(bp5_mf *mf)
     void *pp[] = {q.off, q.dofs, q.sh_dof, q.sh_off, q.sh_slot, q.pos, q.cell_round, q.team_rounds, q.partial, q.cell_off, q.pass_cell, q.pass_off, q.run_off, q.runs, q.gidx, q.packed, q.lattice, q.cell_pos, q.cr_start, q.cr_dof0, q.cr_soff, q.cr_slots, q.cr_tile};
     for (void *x : pp) if (x) hipFree(x);
     if (q.wg_blocks) { for (auto &w : *q.wg_blocks) hipFree(w.second); delete q.wg_blocks; }
+    if (q.cr_carry) {
+      for (auto &c : *q.cr_carry) { void *cc[] = {c.second.start, c.second.dof0, c.second.soff, c.second.slots, c.second.tile}; for (void *x : cc) if (x) hipFree(x); }
+      delete q.cr_carry;
+    }
   }
   if (mf->own_stream) hipStreamDestroy(mf->stream);
   delete mf;
@@ -311,6 +315,18 @@ extern "C" int bp5_mf_block_plan_lattice(bp5_mf *mf, uint32_t *n_lattice_blocks)
   bp5_mf::DevPlan *dp = nullptr;
   BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp, 64));
   *n_lattice_blocks = dp->n_lattice_blocks;
+  return BP5_OK;
+}
+extern "C" int bp5_mf_block_plan_carry(bp5_mf *mf, uint32_t *n_faces, uint32_t *n_shared, uint32_t *n_shared_last_launch)
+{
+  if (!mf || !n_faces || !n_shared || !n_shared_last_launch) return fail(BP5_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(mf->device));
+  bp5_mf::DevPlan *dp = nullptr;
+  BP5_TRY(get_plan_raw(mf, -block_cpt(mf), &dp, 64));
+  *n_faces = 0;
+  for (uint32_t len : dp->h_carry_len) *n_faces += len != 0;
+  *n_shared = dp->n_shared;
+  *n_shared_last_launch = dp->cr_active ? dp->cr_active->n_shared : dp->n_shared;
   return BP5_OK;
 }
 extern "C" int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective)
@@ -584,6 +600,146 @@ static uint32_t detect_lattice_blocks(const uint32_t *l2g, int n, const std::vec
   return n_ok;
 }
 
+// run-length combine tables (runs of consecutive shared DoFs whose contributions sit in consecutive slab slots): start[r] = first ordinal of run r
+// (start[n_runs] = number of shared DoFs), dof0[r] (bit 31: Dirichlet run), slots[soff[r] ...] = the slab slots of the run's first DoF.  Adds the
+// tile table (run containing ordinal COMBINE_TILE t) and one entry of slack, uploads.
+static int upload_combine_tables(std::vector<uint32_t> start, const std::vector<uint32_t> &dof0, std::vector<uint32_t> soff, const std::vector<uint32_t> &slots,
+                                 bp5_mf::DevPlan::CombineTables *ct)
+{
+  const size_t ns = start.back();
+  ct->n_shared = (uint32_t)ns;
+  if (!ns) return BP5_OK;
+  const size_t n_tiles = (ns + COMBINE_TILE - 1) / COMBINE_TILE;
+  std::vector<uint32_t> tile(n_tiles + 1);
+  size_t r = 0;
+  for (size_t t = 0; t <= n_tiles; ++t) { // run containing ordinal min(COMBINE_TILE t, ns - 1)
+    const size_t i = std::min(t * (size_t)COMBINE_TILE, ns - 1);
+    while (start[r + 1] <= i) ++r;
+    tile[t] = (uint32_t)r;
+  }
+  start.push_back((uint32_t)ns); // one entry of slack for the staging loop (reads r_hi + 1)
+  soff.push_back((uint32_t)slots.size());
+  BP5_TRY(upload(&ct->start, start.data(), start.size()));
+  BP5_TRY(upload(&ct->dof0, dof0.data(), dof0.size()));
+  BP5_TRY(upload(&ct->soff, soff.data(), soff.size()));
+  BP5_TRY(upload(&ct->slots, slots.data(), slots.size()));
+  BP5_TRY(upload(&ct->tile, tile.data(), tile.size()));
+  return BP5_OK;
+}
+
+// Face carry (bp5_kernels.hpp: BLOCK_CARRY_MAX).  Block g can hand a face to block g + 1 when the two are lattice blocks that meet in a face whose
+// interior DoFs (a) are ONE shared run in both blocks' lists, (b) are owned, unconstrained and (c) have exactly the two contributions of these
+// blocks, at the slab slots the lists imply.  Two steps around the construction of the run tables: find_carry_faces (a), (b), (c) without the run
+// condition -- the run tables are then CUT at the faces' first and last slots (a run of shared DoFs may span several entities) --, and
+// mark_carry_faces, which checks (a) on the finished tables and writes the carry words of the lattice table (lat) and dp.h_carry_*.
+struct CarryFace { uint32_t dof, len, s_out, s_in; };
+static std::vector<CarryFace> find_carry_faces(const bp5_mf *mf, int p, const TeamPlanHost &h, const std::vector<uint32_t> &lat)
+{
+  const size_t ng = h.off.size() - 1;
+  std::vector<CarryFace> faces(ng, CarryFace{0u, 0u, 0u, 0u});
+  static const int E_OUT[3] = {14, 16, 22}, E_IN[3] = {12, 10, 4}; // entity = eI + 3 eJ + 9 eK, e* in {low face, interior, high face}
+  for (size_t g = 0; g + 1 < ng; ++g) {
+    const uint32_t *ra = lat.data() + g * BLOCK_LATTICE_WORDS, *rb = ra + BLOCK_LATTICE_WORDS;
+    if (!(ra[54] >> 31) || !(rb[54] >> 31)) continue;
+    const uint32_t da[3] = {ra[54] & 0xffu, (ra[54] >> 8) & 0xffu, (ra[54] >> 16) & 0xffu}, db[3] = {rb[54] & 0xffu, (rb[54] >> 8) & 0xffu, (rb[54] >> 16) & 0xffu};
+    for (int d = 0; d < 3; ++d) {
+      const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      if (da[d1] != db[d1] || da[d2] != db[d2]) continue;
+      const uint32_t len = (da[d1] * p - 1) * (da[d2] * p - 1), dof = ra[27 + E_OUT[d]];
+      if (len == 0 || len > (uint32_t)BLOCK_CARRY_MAX || dof != rb[27 + E_IN[d]] || (uint64_t)dof + len > mf->n_owned) continue;
+      const uint32_t s_out = ra[E_OUT[d]], s_in = rb[E_IN[d]];
+      if (s_out > 0xffffu || s_in > 0xffffu) continue;
+      const auto it = std::lower_bound(h.sh_dof.begin(), h.sh_dof.end(), dof);
+      const size_t o = it - h.sh_dof.begin();
+      bool ok = o + len <= h.sh_dof.size();
+      for (uint32_t k = 0; ok && k < len; ++k) {
+        const uint32_t b = h.sh_off[o + k], want_a = h.off[g] + s_out + k, want_b = h.off[g + 1] + s_in + k;
+        ok = h.sh_dof[o + k] == dof + k && h.sh_off[o + k + 1] - b == 2 && !mf->h_constrained[dof + k] &&
+             ((h.sh_slot[b] == want_a && h.sh_slot[b + 1] == want_b) || (h.sh_slot[b] == want_b && h.sh_slot[b + 1] == want_a));
+      }
+      if (!ok) continue;
+      faces[g] = CarryFace{dof, len, s_out, s_in};
+      break;
+    }
+  }
+  return faces;
+}
+static size_t mark_carry_faces(const TeamPlanHost &h, const std::vector<CarryFace> &faces, const std::vector<uint32_t> &run_off, const std::vector<uint32_t> &runs,
+                               std::vector<uint32_t> &lat, bp5_mf::DevPlan &dp)
+{
+  const size_t ng = h.off.size() - 1;
+  dp.h_carry_dof.assign(ng, 0u);
+  dp.h_carry_len.assign(ng, 0u);
+  auto one_shared_run = [&](size_t g, uint32_t slot, uint32_t dof, uint32_t len) {
+    const uint32_t nr = run_off[g + 1] - run_off[g], m = h.off[g + 1] - h.off[g];
+    for (uint32_t r = 0; r < nr; ++r) {
+      const uint32_t s0 = runs[2 * (run_off[g] + r)];
+      if (s0 != slot) continue;
+      const uint32_t s1 = r + 1 < nr ? runs[2 * (run_off[g] + r + 1)] : m;
+      return runs[2 * (run_off[g] + r) + 1] == dof && s1 == slot + len; // (no ownership bit, no Dirichlet bit)
+    }
+    return false;
+  };
+  size_t n_faces = 0;
+  for (size_t g = 0; g + 1 < ng && g < faces.size(); ++g) {
+    const CarryFace &f = faces[g];
+    if (!f.len || !one_shared_run(g, f.s_out, f.dof, f.len) || !one_shared_run(g + 1, f.s_in, f.dof, f.len)) continue;
+    uint32_t *ra = lat.data() + g * BLOCK_LATTICE_WORDS, *rb = ra + BLOCK_LATTICE_WORDS;
+    ra[55] = f.len << 16 | f.s_out; // (list slots < 2^16: the packed indices need that already)
+    rb[56] = f.len << 16 | f.s_in;
+    dp.h_carry_dof[g] = f.dof; dp.h_carry_len[g] = f.len;
+    ++n_faces;
+  }
+  if (!n_faces) { dp.h_carry_dof.clear(); dp.h_carry_len.clear(); }
+  return n_faces;
+}
+
+int build_carry_tables(bp5_mf *mf, bp5_mf::DevPlan *dp, const std::vector<uint32_t> &wb, uint32_t n_wg, bool two_parts, bp5_mf::DevPlan::CombineTables *out)
+{
+  // the faces this partition carries: consecutive blocks inside one part of one workgroup's range (the kernel's rule, apply_block_kernel: c_out)
+  std::vector<std::pair<uint32_t, uint32_t>> cut; // (first DoF, count)
+  for (int part = 0; part < (two_parts ? 2 : 1); ++part) {
+    const uint32_t *w = wb.data() + (size_t)part * (n_wg + 1);
+    for (uint32_t i = 0; i < n_wg; ++i)
+      for (uint32_t g = w[i]; g + 1 < w[i + 1]; ++g)
+        if (dp->h_carry_len[g]) cut.emplace_back(dp->h_carry_dof[g], dp->h_carry_len[g]);
+  }
+  std::sort(cut.begin(), cut.end());
+  const std::vector<uint32_t> &st = dp->h_cr_start, &d0 = dp->h_cr_dof0, &so = dp->h_cr_soff, &sl = dp->h_cr_slots;
+  const size_t nr = d0.size();
+  std::vector<uint32_t> start, dof0, soff, slots;
+  uint32_t ord = 0, owned = 0;
+  size_t ci = 0;
+  auto emit = [&](size_t r, uint32_t first, uint32_t count) { // DoFs [first, first + count) of run r stay
+    if (!count) return;
+    const uint32_t base = d0[r] & 0x7fffffffu;
+    start.push_back(ord);
+    dof0.push_back(first | (d0[r] & 0x80000000u));
+    soff.push_back((uint32_t)slots.size());
+    for (uint32_t q = so[r]; q < so[r + 1]; ++q) slots.push_back(sl[q] + (first - base));
+    ord += count;
+    if (first < mf->n_owned) owned += std::min(count, mf->n_owned - first);
+  };
+  for (size_t r = 0; r < nr; ++r) {
+    uint32_t first = d0[r] & 0x7fffffffu;
+    const uint32_t end = first + (st[r + 1] - st[r]);
+    while (ci < cut.size() && cut[ci].first + cut[ci].second <= first) ++ci;
+    size_t c = ci;
+    while (c < cut.size() && cut[c].first < end) { // (faces are disjoint; each lies inside one run of shared DoFs)
+      const uint32_t c0 = std::max(cut[c].first, first), c1 = std::min(cut[c].first + cut[c].second, end);
+      emit(r, first, c0 - first);
+      first = c1;
+      ++c;
+    }
+    emit(r, first, end - first);
+  }
+  start.push_back(ord);
+  soff.push_back((uint32_t)slots.size());
+  BP5_TRY(upload_combine_tables(start, dof0, soff, slots, out));
+  out->n_shared_owned = owned;
+  return BP5_OK;
+}
+
 // key > 0: uniform teams of `key` cells (team kernel); key < 0: cell blocks walked in passes of
 // -key cells (block kernel) -- the caller's blocks if given, else groups of `default_block` cells
 int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
@@ -602,6 +758,19 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
     BP5_TRY(upload(&dp.dofs, h.dofs.data(), h.dofs.size()));
     std::vector<uint32_t> run_off, runs;
     if (key < 0) {
+      // lattice blocks: recognised and VERIFIED entry by entry here; everything else keeps the packed stream
+      std::vector<uint32_t> lat;
+      std::vector<uint16_t> cpos;
+      const bool lattice_enabled = mf->tune[BP5_TUNE_LATTICE_INDICES] != 0; // (A/B knob, fixed once the plan is built)
+      if (lattice_enabled) dp.n_lattice_blocks = detect_lattice_blocks(mf->h_l2g.data(), mf->degree + 1, h.group_cell_off, h.off, h.dofs, lat, cpos);
+      // ... and the faces consecutive blocks could hand on in LDS (face carry): the run tables are cut at their ends
+      std::vector<CarryFace> faces;
+      if (dp.n_lattice_blocks && dp.n_lattice_blocks == (uint32_t)(h.off.size() - 1)) faces = find_carry_faces(mf, mf->degree, h, lat);
+      auto face_edge = [&](size_t g, uint32_t slot) { // slot = first slot of a carried face of block g, or the first slot behind one
+        if (faces.empty()) return false;
+        if (faces[g].len && (slot == faces[g].s_out || slot == faces[g].s_out + faces[g].len)) return true;
+        return g > 0 && faces[g - 1].len && (slot == faces[g - 1].s_in || slot == faces[g - 1].s_in + faces[g - 1].len);
+      };
       // run-length form of the sorted block lists: consecutive DoFs with equal ownership flag, cut at 512 entries (and where the Dirichlet flag changes) so
       // that (run, offset) packs into 7 + 9 bits
       run_off.assign(h.off.size(), 0);
@@ -610,7 +779,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
         for (uint32_t i = h.off[g]; i < h.off[g + 1]; ++i) {
           const bool con = mf->h_constrained[h.dofs[i] & 0x7fffffffu];
           if (i == h.off[g] || h.dofs[i] != h.dofs[i - 1] + 1 || i - start == (1u << BLOCK_PACK_OFF_BITS) ||
-              con != (bool)mf->h_constrained[h.dofs[i - 1] & 0x7fffffffu]) {
+              con != (bool)mf->h_constrained[h.dofs[i - 1] & 0x7fffffffu] || face_edge(g, i - h.off[g])) {
             start = i;
             runs.push_back(i - h.off[g]);
             runs.push_back(h.dofs[i] | (con ? BLOCK_DOF_CONSTRAINED : 0u)); // bit 31 exclusive (from dofs), bit 30 Dirichlet
@@ -653,17 +822,12 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       BP5_TRY(upload(&dp.pos, pos2.data(), pos2.size()));
       BP5_TRY(upload(&dp.gidx, gidx.data(), gidx.size()));
       if (!packed.empty()) BP5_TRY(upload(&dp.packed, packed.data(), packed.size()));
-      if (!packed.empty()) { // lattice blocks: recognised and VERIFIED entry by entry here; everything else keeps the packed stream
-        std::vector<uint32_t> lat;
-        std::vector<uint16_t> cpos;
-        dp.n_lattice_blocks = detect_lattice_blocks(mf->h_l2g.data(), n, h.group_cell_off, h.off, h.dofs, lat, cpos);
-        const bool lattice_enabled = mf->tune[BP5_TUNE_LATTICE_INDICES] != 0; // (A/B knob, fixed once the plan is built)
-        if (dp.n_lattice_blocks && lattice_enabled) {
-          BP5_TRY(upload(&dp.lattice, lat.data(), lat.size()));
-          BP5_TRY(upload(&dp.cell_pos, cpos.data(), cpos.size()));
-        } else
-          dp.n_lattice_blocks = 0;
-      }
+      if (!packed.empty() && dp.n_lattice_blocks) {
+        if (!faces.empty()) mark_carry_faces(h, faces, run_off, runs, lat, dp);
+        BP5_TRY(upload(&dp.lattice, lat.data(), lat.size()));
+        BP5_TRY(upload(&dp.cell_pos, cpos.data(), cpos.size()));
+      } else
+        dp.n_lattice_blocks = 0;
     } else
       BP5_TRY(upload(&dp.pos, h.pos.data(), h.pos.size()));
     BP5_TRY(upload(&dp.cell_round, h.cell_round.data(), h.cell_round.size()));
@@ -708,21 +872,10 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       }
       start.push_back((uint32_t)ns);
       soff.push_back((uint32_t)slots.size());
-      const size_t n_tiles = (ns + COMBINE_TILE - 1) / COMBINE_TILE;
-      tile.resize(n_tiles + 1);
-      size_t r = 0;
-      for (size_t t = 0; t <= n_tiles; ++t) { // run containing ordinal min(COMBINE_TILE t, ns - 1)
-        const size_t i = std::min(t * (size_t)COMBINE_TILE, ns - 1);
-        while (start[r + 1] <= i) ++r;
-        tile[t] = (uint32_t)r;
-      }
-      start.push_back((uint32_t)ns); // one entry of slack for the staging loop (reads r_hi + 1)
-      soff.push_back((uint32_t)slots.size());
-      BP5_TRY(upload(&dp.cr_start, start.data(), start.size()));
-      BP5_TRY(upload(&dp.cr_dof0, dof0.data(), dof0.size()));
-      BP5_TRY(upload(&dp.cr_soff, soff.data(), soff.size()));
-      BP5_TRY(upload(&dp.cr_slots, slots.data(), slots.size()));
-      BP5_TRY(upload(&dp.cr_tile, tile.data(), tile.size()));
+      bp5_mf::DevPlan::CombineTables ct;
+      BP5_TRY(upload_combine_tables(start, dof0, soff, slots, &ct));
+      dp.cr_start = ct.start; dp.cr_dof0 = ct.dof0; dp.cr_soff = ct.soff; dp.cr_slots = ct.slots; dp.cr_tile = ct.tile;
+      if (!dp.h_carry_len.empty()) { dp.h_cr_start = start; dp.h_cr_dof0 = dof0; dp.h_cr_soff = soff; dp.h_cr_slots = slots; } // (the partitions' tables are cut from these)
     }
     dp.covers_all = h.covers_all;
     dp.n_groups = (uint32_t)h.group_cell_off.size() - 1;
@@ -760,18 +913,24 @@ static uint32_t combine_grid(bp5_mf *mf, uint32_t tiles)
 int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window)
 {
   if (!dp->n_shared) return BP5_OK;
+  // the tables of the block launch this pass follows: the plan's own, or (face carry) its partition's without the carried faces
+  bp5_mf::DevPlan::CombineTables own;
+  own.start = dp->cr_start; own.dof0 = dp->cr_dof0; own.soff = dp->cr_soff; own.slots = dp->cr_slots; own.tile = dp->cr_tile;
+  own.n_shared = dp->n_shared; own.n_shared_owned = dp->n_shared_owned;
+  const bp5_mf::DevPlan::CombineTables &ct = (dp->cr_active && dp->cr_tile && !mf->combine_csr) ? *dp->cr_active : own;
+  if (!ct.n_shared) return BP5_OK;
   if (mf->fuse.on && !(set && dp->cr_tile && !mf->combine_csr)) return fail(BP5_ERR_INVALID, "fused dot products need the run-length combine pass in overwrite mode");
   if (window != COMBINE_ALL && !(dp->cr_tile && !mf->combine_csr)) return fail(BP5_ERR_INVALID, "combine windows need the run-length combine pass");
   if (mf->prof_mark && window != COMBINE_GHOST) { HIP_TRY(hipEventRecord(mf->prof_mark, mf->stream)); mf->prof_mark = nullptr; }
   const dim3 cg((dp->n_shared + 255) / 256); // CSR kernel
   if (dp->cr_tile && !mf->combine_csr) {
     CombineRuns cr{};
-    cr.start = dp->cr_start; cr.dof0 = dp->cr_dof0; cr.soff = dp->cr_soff; cr.slots = dp->cr_slots; cr.tile_run = dp->cr_tile;
-    cr.n_shared = dp->n_shared;
+    cr.start = ct.start; cr.dof0 = ct.dof0; cr.soff = ct.soff; cr.slots = ct.slots; cr.tile_run = ct.tile;
+    cr.n_shared = ct.n_shared;
     // tiles of the window: the shared DoFs are listed in ascending order, owned ones first
-    const uint32_t all_tiles = (dp->n_shared + COMBINE_TILE - 1) / COMBINE_TILE;
-    cr.tile0 = window == COMBINE_GHOST ? dp->n_shared_owned / COMBINE_TILE : 0u;
-    const uint32_t tile1 = window == COMBINE_OWNED ? (dp->n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE : all_tiles;
+    const uint32_t all_tiles = (ct.n_shared + COMBINE_TILE - 1) / COMBINE_TILE;
+    cr.tile0 = window == COMBINE_GHOST ? ct.n_shared_owned / COMBINE_TILE : 0u;
+    const uint32_t tile1 = window == COMBINE_OWNED ? (ct.n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE : all_tiles;
     cr.dof_lo = window == COMBINE_GHOST ? mf->n_owned : 0u;
     cr.dof_hi = window == COMBINE_OWNED ? mf->n_owned : 0xffffffffu;
     if (window == COMBINE_GHOST_THEN_OWNED) {
@@ -779,15 +938,15 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int w
       if (!(mf->fuse.on && set && mf->d_signal)) return fail(BP5_ERR_INVALID, "ghost-rows-first combine launch: fused overwrite launches with a signal word only");
       cr.tile0 = 0u;
       cr.dof_lo = 0u; cr.dof_hi = mf->n_owned;
-      cr.ghost_tile0 = dp->n_shared_owned / COMBINE_TILE;
+      cr.ghost_tile0 = ct.n_shared_owned / COMBINE_TILE;
       cr.ghost_blocks = all_tiles - cr.ghost_tile0;
       cr.signal = mf->d_signal;
-      const uint32_t owned_tiles = (dp->n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE;
+      const uint32_t owned_tiles = (ct.n_shared_owned + COMBINE_TILE - 1) / COMBINE_TILE;
       cr.cg_p = mf->fuse.p; cr.cg_r = mf->fuse.r; cr.dot_partials = mf->d_partials; cr.dot_col0 = mf->fuse.n_cols;
       cr.n_owned = mf->n_owned; cr.n_tiles = owned_tiles; cr.cg_state = mf->d_st;
       if (mf->fuse.n_cols + 1024u + 8u > (uint32_t)PARTIAL_STRIDE) return fail(BP5_ERR_UNSUPPORTED, "no partial-sum columns left for the combine pass");
       const uint32_t grid = combine_grid(mf, owned_tiles);
-      if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      if (ct.n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       else hipLaunchKernelGGL((combine_runs_kernel<false, true, false>), dim3(grid + cr.ghost_blocks), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
       mf->fuse.n_cols += grid;
@@ -803,13 +962,13 @@ int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int w
       if (mf->fuse.n_cols + 1024u + 8u > (uint32_t)PARTIAL_STRIDE) return fail(BP5_ERR_UNSUPPORTED, "no partial-sum columns left for the combine pass");
       const uint32_t grid = combine_grid(mf, cgt.x); // (1024 columns stay free for the exchange)
       // pairs of consecutive ordinals pay on long passes; short ones (config 2, the strong-scaling ranks) are latency-bound
-      if (dp->n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
+      if (ct.n_shared >= (8u << 20)) hipLaunchKernelGGL((combine_runs_kernel<false, true, true>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       else hipLaunchKernelGGL((combine_runs_kernel<false, true, false>), dim3(grid), dim3(256), 0, mf->stream, cr, dp->partial, dst);
       KERNEL_CHECK();
       mf->fuse.n_cols += grid;
       return BP5_OK;
     }
-    const bool pairs = dp->n_shared >= (8u << 20) && window != COMBINE_GHOST;
+    const bool pairs = ct.n_shared >= (8u << 20) && window != COMBINE_GHOST;
     if (set && pairs) hipLaunchKernelGGL((combine_runs_kernel<false, false, true>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     else if (set) hipLaunchKernelGGL((combine_runs_kernel<false, false, false>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
     else if (pairs) hipLaunchKernelGGL((combine_runs_kernel<true, false, true>), cgt, dim3(256), 0, mf->stream, cr, dp->partial, dst);
@@ -1263,6 +1422,7 @@ static void tuning_from_environment(bp5_mf *mf)
   { const int v = env_int("BP5_COMBINE_WG_PER_CU", 16); mf->tune[BP5_TUNE_COMBINE_WG_PER_CU] = (v >= 0 && v <= 32) ? v : 16; }
   mf->tune[BP5_TUNE_INTERIOR_STORES] = env_int("BP5_INTERIOR_STORES", 1) != 0;
   mf->tune[BP5_TUNE_GHOST_COMBINE_ON_COMM] = env_int("BP5_GHOST_COMBINE_ON_COMM", 0) != 0;
+  mf->tune[BP5_TUNE_FACE_CARRY] = env_int("BP5_FACE_CARRY", 1) != 0;
 }
 extern "C" int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value)
 {

@@ -105,7 +105,7 @@ struct bp5_mf {
   int wait_value_ok = -1;     // -1 not probed; 1: hipDeviceAttributeCanUseStreamWaitValue AND the producer / consumer self-check saw a mid-kernel release
   int can_wait_value = -1;    // wait_value_ok and not switched off by BP5_TUNE_BOUNDARY_FIRST = 0
   // per-handle tuning / A-B knobs (bp5.h: BP5_TUNE_*): initial values from the environment, read once by bp5_mf_create
-  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1, 16, 1, 0};
+  int tune[BP5_TUNE_COUNT] = {1, 1, 0, 1, 1, 1, 1, -1, 16, 1, 0, 1};
   bool cell_interiors_first = false; // the mesh numbers the DoFs strictly inside a cell ahead of all others, cell after cell, x fastest (bp5_mesh_desc.dof_numbering = 2)
   // solver workspace
   double *d_partials = nullptr, *d_sc = nullptr, *d_scalar = nullptr;
@@ -146,6 +146,14 @@ struct bp5_mf {
     // interior / boundary ranges of the overlapped schedule alternate, nothing is freed or re-uploaded inside a solve
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t *> *wg_blocks = nullptr; // key: n_wg, first, end, first block of part 0 (0: one part)
     uint32_t *cr_start = nullptr, *cr_dof0 = nullptr, *cr_soff = nullptr, *cr_slots = nullptr, *cr_tile = nullptr; // run-length combine
+    // face carry (BP5_TUNE_FACE_CARRY; bp5_kernels.hpp: BLOCK_CARRY_MAX): which faces stay in LDS depends on the workgroups' block ranges, so the
+    // combine tables WITHOUT the carried faces are kept per partition (the key of wg_blocks); cr_active = the tables the last block launch
+    // asks its combine pass to use (NULL: the plan's own, every shared DoF)
+    struct CombineTables { uint32_t *start = nullptr, *dof0 = nullptr, *soff = nullptr, *slots = nullptr, *tile = nullptr; uint32_t n_shared = 0, n_shared_owned = 0; };
+    std::vector<uint32_t> h_cr_start, h_cr_dof0, h_cr_soff, h_cr_slots; // host form of cr_* (runs, not DoFs: small)
+    std::vector<uint32_t> h_carry_dof, h_carry_len;                      // [n_groups] first DoF / DoF count of the face block g can hand to block g + 1 (0: none)
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, CombineTables> *cr_carry = nullptr;
+    const CombineTables *cr_active = nullptr;
     uint32_t n_shared = 0, n_groups = 0, max_list = 0, max_runs = 0;
     uint32_t n_shared_owned = 0; // shared DoFs are listed in ascending order: ordinals [0, n_shared_owned) are owned DoFs, the rest ghosts
     bool covers_all = false;
@@ -202,6 +210,8 @@ int get_plan(bp5_mf *mf, int cpt, bp5::TeamPlan &tp, bp5_mf::DevPlan **dpo);
 // schedule completes the ghost rows before the interior bricks run); the windows need the run-length form of the pass
 enum { COMBINE_ALL = 0, COMBINE_GHOST = 1, COMBINE_OWNED = 2, COMBINE_GHOST_THEN_OWNED = 3 }; // 3: one launch, ghost rows first + signal (fused solves)
 int launch_combine(bp5_mf *mf, bp5_mf::DevPlan *dp, double *dst, bool set, int window = COMBINE_ALL);
+// combine tables of one workgroup partition without the faces its workgroups carry from brick to brick (wb: the block ranges as uploaded for the kernel)
+int build_carry_tables(bp5_mf *mf, bp5_mf::DevPlan *dp, const std::vector<uint32_t> &wb, uint32_t n_wg, bool two_parts, bp5_mf::DevPlan::CombineTables *out);
 // [c0,c1) == union of whole cell blocks [b0,b1) of the caller's blocking?
 bool block_aligned(const bp5_mf *mf, uint32_t c0, uint32_t c1, uint32_t *b0, uint32_t *b1);
 // Non-temporal accesses to the data a CG iteration touches once (the operator's metric planes; v and x in the update kernel) keep it from evicting
@@ -268,7 +278,7 @@ template <int P, bool COLL, int LPC, int ABL>
 constexpr size_t block_lds_bytes(uint32_t max_list)
 {
   return ((size_t)(256 / LPC) * (size_t)BlockPass<P, COLL, LPC, SC_OWNER_SET, ABL>::TILE_CS + ((ABL & 524288) ? 2 : 1) * (size_t)max_list) * sizeof(double) +
-         ((ABL & 16384) ? (4 * BLOCK_MAX_RUNS + 2 * BLOCK_LATTICE_WORDS) * sizeof(uint32_t) : 0);
+         ((ABL & 16384) ? (4 * BLOCK_MAX_RUNS + 2 * BLOCK_LATTICE_WORDS) * sizeof(uint32_t) : 0) + ((ABL & 268435456) ? 2 * BLOCK_CARRY_MAX * sizeof(double) : 0);
 }
 // ... of the default shape of a degree (sequential tiles, metric loaded in its own pass, run-length write-out, packed indices; the
 // Helmholtz, hanging-node, fused-CG and lattice builds have the same tiles)
@@ -338,7 +348,7 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
     if (!dp->wg_blocks) dp->wg_blocks = new std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t *>;
     auto key = std::make_tuple(n_wg, B0, B1, two_parts ? Bs : 0u);
     auto itw = dp->wg_blocks->find(key);
-    if (itw == dp->wg_blocks->end()) {
+    auto make_ranges = [&]() {
       const std::vector<double> &pc = dp->h_cost;
       std::vector<uint32_t> wb((two_parts ? 2 : 1) * (size_t)(n_wg + 1));
       if (!two_parts) {
@@ -359,11 +369,34 @@ inline int launch_block_t(bp5_mf *mf, const double *coef, const double *src, dou
         }
         wi[0] = B0; wi[n_wg] = Bs;
       }
+      return wb;
+    };
+    if (itw == dp->wg_blocks->end()) {
+      const std::vector<uint32_t> wb = make_ranges();
       uint32_t *dev = nullptr;
       BP5_TRY(upload(&dev, wb.data(), wb.size()));
       itw = dp->wg_blocks->emplace(key, dev).first;
     }
     bp.wg_block = itw->second;
+    // face carry: whole-range owner-store launches of a carry build whose plan found faces to carry; the combine pass of THIS launch then
+    // takes the tables of this partition (dp->cr_active), every other launch the plan's own
+    dp->cr_active = nullptr;
+    if constexpr ((ABL & 268435456) != 0) {
+      const bool atomic_shared_ = mf->block_shared_atomic || (sub_range && !mf->defer_combine);
+      if (mf->tune[BP5_TUNE_FACE_CARRY] && !sub_range && !atomic_shared_ && dp->cr_tile && !mf->combine_csr && !dp->h_carry_len.empty()) {
+        if (!dp->cr_carry) dp->cr_carry = new std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, bp5_mf::DevPlan::CombineTables>;
+        auto itc = dp->cr_carry->find(key);
+        if (itc == dp->cr_carry->end()) {
+          bp5_mf::DevPlan::CombineTables ct;
+          BP5_TRY(build_carry_tables(mf, dp, make_ranges(), n_wg, two_parts, &ct));
+          itc = dp->cr_carry->emplace(key, ct).first;
+        }
+        if (itc->second.n_shared < dp->n_shared) { // (equal: no face of this partition can be carried)
+          dp->cr_active = &itc->second;
+          bp.carry = 1u;
+        }
+      }
+    }
     bp.n_parts = two_parts ? 2u : 1u;
     bp.signal = nullptr;
     if (mf->blk_signal) {
@@ -846,6 +879,7 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 32768>(mf, coef, src, dst, overwrite);
         }
         constexpr int LATT = 16777216; // every block a lattice block: closed-form indices, no per-DoF index stream
+        constexpr int LATC = LATT + 268435456; // ... with the face carry compiled in (BP5_TUNE_FACE_CARRY switches it per launch)
         const bool lattice = (variant == 56 || variant == 63) && dp_->packed && dp_->lattice && dp_->n_lattice_blocks == dp_->n_groups;
         const bool ntm = streaming_accesses(mf); // non-temporal metric loads
 #ifndef BP5_TIMING_BUILDS
@@ -862,17 +896,17 @@ int apply_degree_impl(bp5_mf *mf, const double *coef, const double *src, double 
 #endif
         if (mf->fuse.on) { // the solver asked for the fused dot products (only ever with the packed default shape)
           if (!dp_->packed || variant != 56) return fail(BP5_ERR_INVALID, "fused dot products need the packed block kernel");
-          if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT + 32768>(mf, coef, src, dst, overwrite);
+          if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATC + 32768>(mf, coef, src, dst, overwrite);
           if (lattice)
-            return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite)
-                        : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATT>(mf, coef, src, dst, overwrite);
+            return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATC>(mf, coef, src, dst, overwrite)
+                        : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576 + LATC>(mf, coef, src, dst, overwrite);
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + 1048576>(mf, coef, src, dst, overwrite);
         }
-        if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT + 32768>(mf, coef, src, dst, overwrite);
+        if (lattice && ntm && !coll) return launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATC + 32768>(mf, coef, src, dst, overwrite);
         if (lattice)
-          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite)
-                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATT>(mf, coef, src, dst, overwrite);
+          return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144 + LATC>(mf, coef, src, dst, overwrite)
+                      : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144 + LATC>(mf, coef, src, dst, overwrite);
         if (dp_->packed && variant != 49) // few long runs (block-major numbering): one packed u16 per cell-local DoF, no local_to_global stream
           return coll ? launch_block_t<4, true, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite)
                       : launch_block_t<4, false, 32, 2048 + 8192 + 16384 + 262144>(mf, coef, src, dst, overwrite);

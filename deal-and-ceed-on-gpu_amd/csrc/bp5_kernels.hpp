@@ -1214,7 +1214,13 @@ constexpr int BLOCK_MAX_RUNS = 128;
 // (builds with fused dot products write src there: copy_constrained_values folded into the write-out); DoF indices < 2^30
 constexpr uint32_t BLOCK_DOF_MASK = 0x3fffffffu, BLOCK_DOF_CONSTRAINED = 0x40000000u;
 constexpr int PARTIAL_STRIDE = 8192;   // row length of the partial-sum array d_partials[8][PARTIAL_STRIDE] (all reducing kernels)
-constexpr int BLOCK_LATTICE_WORDS = 64; // per block: 27 entity slots, 27 entity DoFs, dims | flag, padding (bp5_device.hip: detect_lattice_blocks)
+constexpr int BLOCK_LATTICE_WORDS = 64; // per block: 27 entity slots, 27 entity DoFs, dims | flag, face-carry words, padding (bp5_device.hip: detect_lattice_blocks)
+// face carry (builds with ABL & 268435456): when block g + 1 of the plan is the neighbour of block g across a face whose interior DoFs the two
+// share with nobody else, and one workgroup walks both, the face's partial sums stay in LDS from the write-out of g to the write-out of
+// g + 1, which stores p(g + 1) + p(g) as an owner store -- the bits of the combine pass's p(g) + p(g + 1) without the slab round trip.
+// Lattice words of block g: [55] = face DoFs << 16 | first list slot of the face g can hand to g + 1 (0: none), [56] = the same for the face g
+// shares with g - 1 (set when [55] of g - 1 is).
+constexpr int BLOCK_CARRY_MAX = 225;    // face DoFs that can be carried (a 4x4 face at p = 4: 15 x 15)
 constexpr int BLOCK_PACK_OFF_BITS = 9;                              // packed index = run << 9 | offset (runs are cut at 512 entries)
 constexpr int BLOCK_PACK_MAX_RUNS = 1 << (16 - BLOCK_PACK_OFF_BITS); // 128 == BLOCK_MAX_RUNS
 static_assert(BLOCK_PACK_MAX_RUNS <= BLOCK_MAX_RUNS, "the LDS run table holds every packable run");
@@ -1250,6 +1256,7 @@ struct BlockPlan {
   const uint32_t *run_off;    // [n_blocks+1]
   const uint32_t *runs;       // [2 * run_off[n_blocks]]
   uint32_t max_list;          // longest block list (the accumulator's size in LDS)
+  uint32_t carry;             // face-carry builds: 1 = carry (the combine tables of this launch leave the carried faces out), 0 = every shared DoF to the slab
   unsigned long long *stamps; // diagnostic builds only: [n_wg][16] cycle sums per phase (never read by kernels)
   // builds with ABL & 1048576 (fused CG dot products, SolverCGFullMerge's update_b, bp5/solver.h:142-311): src == p, dst == v
   const double *cg_r;         // residual vector r
@@ -2024,6 +2031,14 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
   uint32_t *const lat_tab = run_tab + 4 * BLOCK_MAX_RUNS;
   constexpr bool use_lattice = BP::LATT;
   uint32_t lat_word = 0;
+  // face carry: two buffers (block parity: the write-out of block b reads the one block b - 1 filled and fills the other)
+  constexpr bool CARRY = (ABL & 268435456) != 0;
+  static_assert(!CARRY || (BP::LATT && RUNS), "face carry: lattice blocks with run tables");
+  double *const carry_buf = reinterpret_cast<double *>(lat_tab + 2 * BLOCK_LATTICE_WORDS);
+  bool c_carried = false;             // the previous block of this workgroup handed its face on
+  uint32_t c_in_w = 0, c_out_w = 0;   // write-out of the current block: DoFs << 16 | first slot of the face taken over / handed on (0: none)
+  auto c_in_at = [&](int i) { return (uint32_t)(i - (int)(c_in_w & 0xffffu)) < (c_in_w >> 16); };
+  auto c_out_at = [&](int i) { return (uint32_t)(i - (int)(c_out_w & 0xffffu)) < (c_out_w >> 16); };
   uint32_t r0 = RUNS ? bp.run_off[pb] : 0u;
   int n_runs = RUNS ? (int)(bp.run_off[pb + 1] - r0) : 0;
   uint32_t run_slot = 0, run_dof = 0;
@@ -2130,9 +2145,19 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
       }
     }
   };
+  // face carry: a slot of the face taken over from the previous block is an owner slot here (carry_mark sets bit 31 of its run word in the
+  // walks below) and its value is this block's sum + the carried one; a slot of the face handed on goes to the carry buffer, not the slab
+  auto carry_mark = [&](int i, uint32_t g) -> uint32_t {
+    if constexpr (CARRY) { if (c_in_at(i)) return g | 0x80000000u; }
+    return g;
+  };
   auto emit = [&](int i, uint32_t g, double ri = 0.0) { // ri: DOTS builds, r[g] loaded ahead of the stores
-    const double v = acc[i];
+    double v = acc[i];
     acc[i] = 0.0; // re-arm for the next block (invariant: the accumulator is all zero between blocks)
+    if constexpr (CARRY) {
+      if (c_in_at(i)) v += carry_buf[((b + 1) & 1u) * BLOCK_CARRY_MAX + (i - (int)(c_in_w & 0xffffu))];
+      if (c_out_at(i)) { carry_buf[(b & 1u) * BLOCK_CARRY_MAX + (i - (int)(c_out_w & 0xffffu))] = v; return; }
+    }
     if (g & 0x80000000u) {
       const uint32_t gi = g & BLOCK_DOF_MASK;
       if constexpr (DOTS) {
@@ -2160,9 +2185,20 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
   };
   // two consecutive list slots of one run: 16-byte LDS read, 16-byte global store (half the store instructions)
   auto emit2 = [&](int i, uint32_t g, bp5_d2u rv = bp5_d2u{0.0, 0.0}) {
-    const double v0 = acc[i], v1 = acc[i + 1];
+    double v0 = acc[i], v1 = acc[i + 1];
     acc[i] = 0.0;
     acc[i + 1] = 0.0;
+    if constexpr (CARRY) { // (a carried face is exactly one run: both slots of the pair or none)
+      if (c_in_at(i)) {
+        const double *cb = carry_buf + ((b + 1) & 1u) * BLOCK_CARRY_MAX + (i - (int)(c_in_w & 0xffffu));
+        v0 += cb[0]; v1 += cb[1];
+      }
+      if (c_out_at(i)) {
+        double *cb = carry_buf + (b & 1u) * BLOCK_CARRY_MAX + (i - (int)(c_out_w & 0xffffu));
+        cb[0] = v0; cb[1] = v1;
+        return;
+      }
+    }
     if (g & 0x80000000u) {
       const uint32_t gi = g & BLOCK_DOF_MASK;
       double *d = a.dst + gi;
@@ -2213,6 +2249,14 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
         }
       }
       __syncthreads(); // every wave has added its last contributions of this block
+      if constexpr (CARRY) {
+        const uint32_t *lt = lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS;
+        uint32_t wo = 0u, wi = 0u;
+        if (bp.carry) { wo = lt[55]; wi = lt[56]; }
+        // the successor must be the next block of the SAME part of this workgroup's range (the host applies the same rule to the combine tables)
+        c_out_w = (b + 1 < b1 && b + 1 != nba) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wo) : 0u;
+        c_in_w = c_carried ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wi) : 0u;
+      }
       if constexpr (DOTS) {
         // as below, in batches of NW pairs per thread: first the run walk and ALL the batch's loads of r (they are
         // independent: one memory latency per batch instead of one per pair), then the stores and the dot products
@@ -2231,7 +2275,7 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
             rv[j] = bp5_d2u{0.0, 0.0};
             if (i < m) {
               while (r + 1 < n_runs && (int)rt[r + 1] <= i) ++r;
-              g0[j] = rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]);
+              g0[j] = carry_mark(i, rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]));
               const bool run_ends = r + 1 < n_runs && (int)rt[r + 1] == i + 1;
               const uint32_t gi = g0[j] & BLOCK_DOF_MASK; // (every DoF of a list is < n_local: the vectors hold owned + ghost entries)
               if (i + 1 < m && !run_ends) {
@@ -2242,7 +2286,7 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
                 if (has_r && (g0[j] & 0x80000000u)) rv[j].x = bp.cg_r[gi];
                 if (i + 1 < m) {
                   kind[j] = 3;
-                  g1[j] = rt[BLOCK_MAX_RUNS + r + 1];
+                  g1[j] = carry_mark(i + 1, rt[BLOCK_MAX_RUNS + r + 1]);
                   if (has_r && (g1[j] & 0x80000000u)) rv[j].y = bp.cg_r[g1[j] & BLOCK_DOF_MASK];
                 }
               }
@@ -2263,12 +2307,12 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
         int r = 0;
         for (int i = 2 * t; i < m; i += 2 * TEAM) {
           while (r + 1 < n_runs && (int)rt[r + 1] <= i) ++r;
-          const uint32_t g = rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]);
+          const uint32_t g = carry_mark(i, rt[BLOCK_MAX_RUNS + r] + (uint32_t)(i - (int)rt[r]));
           const bool run_ends = r + 1 < n_runs && (int)rt[r + 1] == i + 1;
           if (i + 1 < m && !run_ends) emit2(i, g);
           else {
             emit(i, g);
-            if (i + 1 < m) emit(i + 1, rt[BLOCK_MAX_RUNS + r + 1]); // first slot of the next run
+            if (i + 1 < m) emit(i + 1, carry_mark(i + 1, rt[BLOCK_MAX_RUNS + r + 1])); // first slot of the next run
           }
         }
       }
@@ -2287,6 +2331,7 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
             if (base + r * TEAM < m) emit(base + r * TEAM, g8[r]);
         }
       }
+      if constexpr (CARRY) c_carried = c_out_w != 0u;
       ++b;
       if (bp.signal && b == nba) signal_part_done(true);            // the last ghost-touching brick of this workgroup is written out
       if (b < b1) {

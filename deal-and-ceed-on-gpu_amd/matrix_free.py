@@ -160,7 +160,7 @@ class MatrixFree:
         _lib.check(_lib.lib().bp5_mf_set_streaming(self.handle, int(policy)))
 
     TUNE = {"lattice_indices": 0, "early_gather": 1, "combine_signal": 2, "boundary_first": 3, "fold_small": 4, "update_unroll": 5,
-            "update_flat": 6, "update_nt": 7, "combine_wg_per_cu": 8, "interior_stores": 9, "ghost_combine_on_comm": 10}   # bp5.h: BP5_TUNE_*
+            "update_flat": 6, "update_nt": 7, "combine_wg_per_cu": 8, "interior_stores": 9, "ghost_combine_on_comm": 10, "face_carry": 11}   # bp5.h: BP5_TUNE_*
 
     def set_tuning(self, knob, value):
         """Per-handle A/B knob (bp5.h BP5_TUNE_*; same bits for every setting); knob by name or number."""
@@ -188,6 +188,12 @@ class MatrixFree:
         n = C.c_uint32()
         _lib.check(_lib.lib().bp5_mf_block_plan_lattice(self.handle, C.byref(n)))
         return n.value
+
+    def block_plan_carry(self):
+        """(faces the plan can carry in LDS from block to block, brick-surface DoFs, brick-surface DoFs in the combine tables of the last block launch)"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.lib().bp5_mf_block_plan_carry(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def get_apply_variant(self):
         """The kernel variant a whole-range application resolves to (what 0 = default means here)."""

@@ -290,10 +290,14 @@ int bp5_mf_set_streaming(bp5_mf *mf, int policy);
  *   BP5_TUNE_GHOST_COMBINE_ON_COMM (env BP5_GHOST_COMBINE_ON_COMM, default 0) default exchange schedule (overlap 2): the ghost-row window of the combine pass on the
  *                              communication stream (in front of the send) instead of the compute stream, so that the owned-row window starts right behind the brick kernel.
  *   BP5_TUNE_INTERIOR_STORES   (env BP5_INTERIOR_STORES, default 1) atomic pencil kernel of p >= 5 on a mesh whose cell-interior DoFs are numbered ahead of all
- *                              others (bp5_mesh_desc.dof_numbering = 2; detected at bp5_mf_create): plain stores for the (p-1)^3 entries a cell owns alone. */
+ *                              others (bp5_mesh_desc.dof_numbering = 2; detected at bp5_mf_create): plain stores for the (p-1)^3 entries a cell owns alone.
+ *   BP5_TUNE_FACE_CARRY        (env BP5_FACE_CARRY, default 1) block kernel on lattice bricks (p = 4): the interior of the face two CONSECUTIVE bricks of one
+ *                              workgroup's range share stays in LDS from the first brick's write-out to the second's, which stores the sum as an owner store;
+ *                              the combine pass of that launch skips those DoFs.  v is the same bits as without (a + b == b + a); the fused dot products are
+ *                              summed over other workgroups (rounding-level differences, reproducible run to run). */
 enum { BP5_TUNE_LATTICE_INDICES = 0, BP5_TUNE_EARLY_GATHER = 1, BP5_TUNE_COMBINE_SIGNAL = 2, BP5_TUNE_BOUNDARY_FIRST = 3,
        BP5_TUNE_FOLD_SMALL = 4, BP5_TUNE_UPDATE_UNROLL = 5, BP5_TUNE_UPDATE_FLAT = 6, BP5_TUNE_UPDATE_NT = 7, BP5_TUNE_COMBINE_WG_PER_CU = 8,
-       BP5_TUNE_INTERIOR_STORES = 9, BP5_TUNE_GHOST_COMBINE_ON_COMM = 10, BP5_TUNE_COUNT = 11 };
+       BP5_TUNE_INTERIOR_STORES = 9, BP5_TUNE_GHOST_COMBINE_ON_COMM = 10, BP5_TUNE_FACE_CARRY = 11, BP5_TUNE_COUNT = 12 };
 int bp5_mf_set_tuning(bp5_mf *mf, int knob, int value);
 int bp5_mf_get_tuning(const bp5_mf *mf, int knob, int *value);
 /* 1 when the in-launch stream wait-value schedules are available on this handle (capability + self-check, see BP5_TUNE_BOUNDARY_FIRST);
@@ -308,6 +312,10 @@ int bp5_mf_block_plan_info(bp5_mf *mf, uint32_t *n_blocks, uint32_t *max_runs, i
  * entry's list slot and DoF in closed form from the cell's position in its block and reads no per-DoF index at all (the packed stream of
  * the other blocks costs 2 bytes per cell-local DoF); the results are bitwise the same either way. */
 int bp5_mf_block_plan_lattice(bp5_mf *mf, uint32_t *n_lattice_blocks);
+/* ... and the face carry (BP5_TUNE_FACE_CARRY): faces the plan found that a workgroup may keep in LDS from one block to the next, the plan's
+ * brick-surface (shared) DoFs, and how many of those the combine pass of the LAST block-kernel launch on this handle had in its tables
+ * (== n_shared when that launch carried nothing). */
+int bp5_mf_block_plan_carry(bp5_mf *mf, uint32_t *n_faces, uint32_t *n_shared, uint32_t *n_shared_last_launch);
 /* the variant a whole-range application resolves to (what "0" means for this handle) */
 int bp5_mf_get_apply_variant(bp5_mf *mf, int *effective);
 

@@ -535,6 +535,58 @@ def test_tuning_knobs_are_fields_of_the_handle_and_change_no_bit():
     assert isinstance(mf.wait_value_available(), bool)   # (creates the communication stream and runs the producer / consumer self-check)
 
 
+@pytest.mark.parametrize("cells,block,kw", [((13, 8, 6), (4, 4, 4), {}), ((48, 4, 4), (4, 4, 4), {}), ((8, 8, 12), (4, 4, 2), dict(rank=1, n_ranks=2)),
+                                            ((13, 9, 9), (4, 4, 4), dict(rank=1, n_ranks=3))])
+def test_face_carry_keeps_shared_faces_in_lds_and_changes_no_bit_of_v(cells, block, kw):
+    """BP5_TUNE_FACE_CARRY (round 4): the interior of the face two consecutive bricks of one workgroup's range share stays in LDS from
+    the first brick's write-out to the second's, which stores p1 + p0 as an owner store; the combine pass of that launch walks tables without those
+    DoFs.  v = A u is bitwise the result without the carry (p0 + p1), in overwrite and in accumulate mode, for every workgroup count (the carried set
+    depends on the partition, the sums do not); the merged solver (its dot products take the carried DoFs from another kernel: rounding-level
+    differences) is reproducible run to run and agrees to 1e-12.  Full and partial bricks, a slab with its ghost plane."""
+    torch = _t()
+    mesh = pkg.BrickMesh(4, cells, h=0.2, deform_amp=0.03, cell_block=block, dof_numbering=1, cell_block_order=1, **kw)
+    op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
+    mf = op.mf_data
+    mf.set_apply_variant(56)
+    assert mf.get_tuning("face_carry") in (0, 1)
+    faces, n_shared, _ = mf.block_plan_carry()
+    assert faces > 0 and n_shared > 0
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    u = torch.rand(mf.n_local, dtype=torch.float64, device="cuda:0", generator=g)
+    w0 = torch.rand(mf.n_local, dtype=torch.float64, device="cuda:0", generator=g)
+    ref = None
+    for n_wg in (8, 16, 0):
+        mf.set_block_workgroups(n_wg)
+        for carry in (0, 1):
+            mf.set_tuning("face_carry", carry)
+            v = op.initialize_dof_vector(); op.vmult(v, u)
+            in_tables = mf.block_plan_carry()[2]
+            assert in_tables == n_shared if not carry else in_tables < n_shared if n_wg == 8 else in_tables <= n_shared   # (8 workgroups: several bricks each)
+            op.do_zero_out = False
+            w = w0.clone(); op.vmult(w, u)
+            op.do_zero_out = True
+            if ref is None:
+                ref = (v.clone(), w.clone())
+            assert torch.equal(v, ref[0]) and torch.equal(w, ref[1]), (n_wg, carry)
+    if kw:
+        return      # (a slab without its neighbours: operator only)
+    mf.set_block_workgroups(8)
+    b = op.assemble_rhs()
+    xs = {}
+    for carry in (0, 1, 1):
+        mf.set_tuning("face_carry", carry)
+        x = op.initialize_dof_vector()
+        pkg.SolverCGFullMerge(pkg.IterationNumberControl(9, 0.0)).solve(op, x, b, pkg.DiagonalMatrix())
+        if carry in xs:
+            assert torch.equal(xs[carry], x)            # same bits run to run
+        xs[carry] = x
+    assert mf.block_plan_carry()[2] < n_shared              # the fused solve carried
+    assert torch.allclose(xs[0], xs[1], rtol=1e-12, atol=1e-14 * float(xs[0].abs().max()))
+    xp = op.initialize_dof_vector()
+    pkg.SolverCG(pkg.IterationNumberControl(9, 0.0)).solve(op, xp, b, pkg.DiagonalMatrix())
+    assert torch.allclose(xp, xs[1], rtol=1e-9, atol=1e-11 * float(xp.abs().max()))
+
+
 def test_set_operator_is_refused_once_the_metric_array_is_sized():
     """bp5_mf_set_operator(BP5_OP_HELMHOLTZ) after the caller sized or filled a six-plane metric array would make every later kernel read a
     seventh plane out of bounds -- the handle remembers the plane count it handed out and refuses the switch (either direction)."""

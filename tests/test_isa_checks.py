@@ -50,9 +50,9 @@ def test_default_operator_kernels_do_not_spill():
     text = "".join(open(f).read() for f in _isa())
     want = {"apply_block_kernelILi4ELb0ELi32ELi1ELi288768E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi288768E": 168,
             "apply_block_kernelILi4ELb0ELi32ELi1ELi1337344E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi1337344E": 168,   # + fused CG dot products
-            "apply_block_kernelILi4ELb0ELi32ELi1ELi18114560E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi18114560E": 168,  # ... on lattice blocks (the bench's kernel)
-            "apply_block_kernelILi4ELb0ELi32ELi1ELi17065984E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi17065984E": 168,
-            "apply_block_kernelILi4ELb0ELi32ELi1ELi18147328E": 168, "apply_block_kernelILi4ELb0ELi32ELi1ELi17098752E": 168,   # ... with non-temporal metric loads (<= 2.4e7 local DoFs)
+            "apply_block_kernelILi4ELb0ELi32ELi1ELi286550016E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi286550016E": 168,  # ... on lattice blocks, face carry compiled in (the bench's kernel)
+            "apply_block_kernelILi4ELb0ELi32ELi1ELi285501440E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi285501440E": 168,
+            "apply_block_kernelILi4ELb0ELi32ELi1ELi286582784E": 168, "apply_block_kernelILi4ELb0ELi32ELi1ELi285534208E": 168,   # ... with non-temporal metric loads (<= 2.4e7 local DoFs)
             "apply_block_kernelILi4ELb0ELi32ELi1ELi26624E": 168, "apply_block_kernelILi4ELb1ELi32ELi1ELi26624E": 168,
             "apply_pencil_kernelILi4ELb0ELi4ELi25ELi1ELb1ELi0E": 168}
     for key, max_vgpr in want.items():
