@@ -762,7 +762,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       std::vector<uint32_t> lat;
       std::vector<uint16_t> cpos;
       const bool lattice_enabled = mf->tune[BP5_TUNE_LATTICE_INDICES] != 0; // (A/B knob, fixed once the plan is built)
-      if (lattice_enabled) dp.n_lattice_blocks = detect_lattice_blocks(mf->h_l2g.data(), mf->degree + 1, h.group_cell_off, h.off, h.dofs, lat, cpos);
+      dp.n_lattice_blocks = detect_lattice_blocks(mf->h_l2g.data(), mf->degree + 1, h.group_cell_off, h.off, h.dofs, lat, cpos);
       // ... and the faces consecutive blocks could hand on in LDS (face carry): the run tables are cut at their ends
       std::vector<CarryFace> faces;
       if (dp.n_lattice_blocks && dp.n_lattice_blocks == (uint32_t)(h.off.size() - 1)) faces = find_carry_faces(mf, mf->degree, h, lat);
@@ -822,7 +822,7 @@ int get_plan_raw(bp5_mf *mf, int key, bp5_mf::DevPlan **dpo, int default_block)
       BP5_TRY(upload(&dp.pos, pos2.data(), pos2.size()));
       BP5_TRY(upload(&dp.gidx, gidx.data(), gidx.size()));
       if (!packed.empty()) BP5_TRY(upload(&dp.packed, packed.data(), packed.size()));
-      if (!packed.empty() && dp.n_lattice_blocks) {
+      if (!packed.empty() && dp.n_lattice_blocks && lattice_enabled) { // (knob off: the same run tables, cuts included -- the two builds give the same bits)
         if (!faces.empty()) mark_carry_faces(h, faces, run_off, runs, lat, dp);
         BP5_TRY(upload(&dp.lattice, lat.data(), lat.size()));
         BP5_TRY(upload(&dp.cell_pos, cpos.data(), cpos.size()));

@@ -2166,10 +2166,12 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
         double vi = v;
         if (g & BLOCK_DOF_CONSTRAINED) {
           vi = a.src[gi];
-          if (gi < bp.n_owned) ds[0] += vi * (vi - v);
+          if (gi < bp.n_owned) ds[0] = __builtin_fma(vi, vi - v, ds[0]);
         }
         __builtin_nontemporal_store(vi, a.dst + gi);
-        if (gi < bp.n_owned) { ds[1] += vi * vi; ds[2] += ri * vi; ds[3] += ri * ri; }
+        // (explicit fused multiply-adds, here and in emit2: left to the compiler's contraction, `s += a a + b b` rounds differently from one
+        // build of this kernel to the next -- the packed and the lattice build must give the same bits)
+        if (gi < bp.n_owned) { ds[1] = __builtin_fma(vi, vi, ds[1]); ds[2] = __builtin_fma(ri, vi, ds[2]); ds[3] = __builtin_fma(ri, ri, ds[3]); }
       } else if constexpr (ABL & 16) { if (v == 1.2345e300) a.dst[gi] = v; }
       else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
         if constexpr (ABL & 65536) a.dst[gi] = v;
@@ -2207,12 +2209,12 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
         if (g & BLOCK_DOF_CONSTRAINED) { // see emit(): Dirichlet rows
           const bp5_d2u pv = *reinterpret_cast<const bp5_d2u *>(a.src + gi);
           w0 = pv.x; w1 = pv.y;
-          if (gi < bp.n_owned) ds[0] += w0 * (w0 - v0);
-          if (gi + 1 < bp.n_owned) ds[0] += w1 * (w1 - v1);
+          if (gi < bp.n_owned) ds[0] = __builtin_fma(w0, w0 - v0, ds[0]);
+          if (gi + 1 < bp.n_owned) ds[0] = __builtin_fma(w1, w1 - v1, ds[0]);
         }
         __builtin_nontemporal_store(bp5_d2u{w0, w1}, reinterpret_cast<bp5_d2u *>(d));
-        if (gi + 1 < bp.n_owned) { ds[1] += w0 * w0 + w1 * w1; ds[2] += rv.x * w0 + rv.y * w1; ds[3] += rv.x * rv.x + rv.y * rv.y; }
-        else if (gi < bp.n_owned) { ds[1] += w0 * w0; ds[2] += rv.x * w0; ds[3] += rv.x * rv.x; } // the pair straddles the end of the owned range
+        if (gi < bp.n_owned) { ds[1] = __builtin_fma(w0, w0, ds[1]); ds[2] = __builtin_fma(rv.x, w0, ds[2]); ds[3] = __builtin_fma(rv.x, rv.x, ds[3]); }
+        if (gi + 1 < bp.n_owned) { ds[1] = __builtin_fma(w1, w1, ds[1]); ds[2] = __builtin_fma(rv.y, w1, ds[2]); ds[3] = __builtin_fma(rv.y, rv.y, ds[3]); } // (a pair may straddle the end of the owned range)
       } else if constexpr (SCATTER == SC_OWNER_SET || SCATTER == SC_OWNER_SET_ATOMIC) {
         if constexpr (ABL & 65536) { d[0] = v0; d[1] = v1; }
         else __builtin_nontemporal_store(bp5_d2u{v0, v1}, reinterpret_cast<bp5_d2u *>(d));

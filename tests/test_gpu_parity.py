@@ -615,6 +615,7 @@ def test_lattice_blocks_need_no_index_stream(p, cells, block, kw):
     for lattice in (1, 0):
         op = pkg.PoissonOperator(mesh, 0, pkg.COEF_STEP64)
         op.mf_data.set_tuning("lattice_indices", lattice)          # a knob of the HANDLE (two handles of one process differ here), fixed once the plan is built
+        op.mf_data.set_tuning("face_carry", 0)                     # (p = 4 lattice build: the carried faces' dot-product terms would be summed by another kernel -- v is the same bits, the solve is not)
         op.mf_data.set_apply_variant(56)
         op.mf_data.set_block_workgroups(8)
         nb, _, packed = op.mf_data.block_plan_info()
