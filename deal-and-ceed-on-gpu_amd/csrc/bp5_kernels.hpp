@@ -1290,6 +1290,20 @@ __device__ __forceinline__ unsigned long long stamp_now()
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+// wave priority per phase of a pass (probes: -DBP5_PRIO_Q=k ... ; -1: no instruction)
+#ifndef BP5_PRIO_Q
+#define BP5_PRIO_Q -1
+#endif
+#ifndef BP5_PRIO_I
+#define BP5_PRIO_I -1
+#endif
+#ifndef BP5_PRIO_A
+#define BP5_PRIO_A -1
+#endif
+#ifndef BP5_PRIO_END
+#define BP5_PRIO_END -1
+#endif
+#define BP5_PRIO_PHASE(k) if constexpr ((k) >= 0) __builtin_amdgcn_s_setprio((k) < 0 ? 0 : (k));
 #define BP5_STAMP(slot)                                                                                            \
   if constexpr (ABL & 4096) {                                                                                      \
     const unsigned long long now_ = stamp_now();                                                                   \
@@ -1837,6 +1851,7 @@ struct BlockPass {
     // the index loads of the next pass have landed by now: start its src gather
     if constexpr (!PACK) issue_gather(a, nxt);
     BP5_STAMP(2) // wait for the next pass's indices + issue of its gather
+    BP5_PRIO_PHASE(BP5_PRIO_Q)
 
 #pragma unroll
     for (int i = 0; i < n; ++i) {
@@ -1854,6 +1869,7 @@ struct BlockPass {
     }
 
     BP5_STAMP(3) // quadrature-point operation (first use of the metric: waits for its loads)
+    BP5_PRIO_PHASE(BP5_PRIO_I)
     double y[n];
     if constexpr (ABL & 8) {
 #pragma unroll
@@ -1912,6 +1928,7 @@ struct BlockPass {
     }
 
     BP5_STAMP(4) // integrate
+    BP5_PRIO_PHASE(BP5_PRIO_A)
     // accumulate into the block's LDS vector; cells of one round share no DoF (normally the
     // whole pass is one round: host packing, bp5_host.cpp)
     // One block barrier per round, BEFORE the update: it orders this pass's accumulation after the previous
@@ -1933,6 +1950,7 @@ struct BlockPass {
       __syncthreads();
     }
     BP5_STAMP(5) // accumulate
+    BP5_PRIO_PHASE(BP5_PRIO_END)
 #undef TL
   }
 };
@@ -1957,6 +1975,23 @@ constexpr int block_wg_per_cu()
   if (P == 2 && BP5_WAVE_PACK != 0 && !(ABL & 2097152) && !(ABL & 1024)) return BP5_WG_PER_CU_P2; // (wave-packed cells: one tile per slot, 36 KB of LDS on 8x8x4 bricks, 126 VGPRs)
   return 3;
 }
+// wave priority (round 4): the instructions that ISSUE a pass's loads (metric planes, indices, gather) and the write-out of a block run at s_setprio 3, the
+// arithmetic at 0 -- a wave about to put memory requests in flight goes ahead of the waves of the other workgroups on its SIMD that are computing.  Rotating
+// A/B of two builds, one box per comparison (profiles/r4/x_wave_priority_ab.txt): fused p = 4 kernel 2.649 -> 2.572, 2.770 -> 2.738, 2.768 -> 2.721, 2.619 -> 2.562 ms -- and
+// 2.548 -> 2.586 on one box of six; either bracket alone gains nothing, raising the priority towards the accumulation barrier as well (BP5_PRIO_Q / _I / _A
+// below) nothing more.  Compile-time (-DBP5_SETPRIO=0 -DBP5_SETPRIO_WO=0 rebuilds the
+// old code): a run-time switch around s_setprio costs the headline build 15 spilled registers.
+#ifndef BP5_SETPRIO
+#define BP5_SETPRIO 3
+#endif
+#ifndef BP5_SETPRIO_WO
+#define BP5_SETPRIO_WO 3
+#endif
+// (lattice builds only: measured there; the packed-index build of p = 4 sits at its 168 registers and would spill two)
+#define BP5_PRIO_HI if constexpr (BP5_SETPRIO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(BP5_SETPRIO);
+#define BP5_PRIO_LO if constexpr (BP5_SETPRIO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(0);
+#define BP5_PRIO_WO_HI if constexpr (BP5_SETPRIO_WO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(BP5_SETPRIO_WO);
+#define BP5_PRIO_WO_LO if constexpr (BP5_SETPRIO_WO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(0);
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
 __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
@@ -2251,6 +2286,7 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
         }
       }
       __syncthreads(); // every wave has added its last contributions of this block
+      BP5_PRIO_WO_HI
       if constexpr (CARRY) {
         const uint32_t *lt = lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS;
         uint32_t wo = 0u, wi = 0u;
@@ -2334,6 +2370,7 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
         }
       }
       if constexpr (CARRY) c_carried = c_out_w != 0u;
+      BP5_PRIO_WO_LO
       ++b;
       if (bp.signal && b == nba) signal_part_done(true);            // the last ghost-touching brick of this workgroup is written out
       if (b < b1) {
@@ -2360,21 +2397,21 @@ __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_
 
   while (gp < gp_end) {
     prefetch_list();
-    BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end);
+    BP5_PRIO_HI BP::issue_loads(a, bp, B, abm, lane_ok, gp + 1 < gp_end); BP5_PRIO_LO
     const uint32_t entA2 = entry(gp + 2);
     BP::run(a, sh, A, B, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0], Sroll);
     finish_pass();
     BP5_STAMP(6) // block boundary: write-out + re-arm (zero in passes that do not end a block)
     if (gp >= gp_end) break;
-    if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); // b: block of the next pass
+    BP5_PRIO_HI if constexpr (BP::PACK) BP::decode_and_gather(a, B, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); // b: block of the next pass BP5_PRIO_LO
     A.ent = entA2;
     prefetch_list();
-    BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end);
+    BP5_PRIO_HI BP::issue_loads(a, bp, A, abm, lane_ok, gp + 1 < gp_end); BP5_PRIO_LO
     const uint32_t entB2 = entry(gp + 2);
     BP::run(a, sh, B, A, T, acc, a_, b_, n_rounds, abm, ph, tprev, ds[0], Sroll);
     finish_pass();
     BP5_STAMP(6)
-    if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); }
+    BP5_PRIO_HI if constexpr (BP::PACK) { if (gp < gp_end) BP::decode_and_gather(a, A, run_tab + (b & 1u) * (2 * BLOCK_MAX_RUNS), staged, use_lattice ? lat_tab + (b & 1u) * BLOCK_LATTICE_WORDS : nullptr, a_, b_); } BP5_PRIO_LO
     B.ent = entB2;
   }
   if constexpr (DOTS) {
