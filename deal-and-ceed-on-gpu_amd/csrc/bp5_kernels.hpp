@@ -1987,11 +1987,12 @@ constexpr int block_wg_per_cu()
 #ifndef BP5_SETPRIO_WO
 #define BP5_SETPRIO_WO 3
 #endif
-// (lattice builds only: measured there; the packed-index build of p = 4 sits at its 168 registers and would spill two)
-#define BP5_PRIO_HI if constexpr (BP5_SETPRIO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(BP5_SETPRIO);
-#define BP5_PRIO_LO if constexpr (BP5_SETPRIO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(0);
-#define BP5_PRIO_WO_HI if constexpr (BP5_SETPRIO_WO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(BP5_SETPRIO_WO);
-#define BP5_PRIO_WO_LO if constexpr (BP5_SETPRIO_WO != 0 && BP::LATT) __builtin_amdgcn_s_setprio(0);
+// (lattice and Helmholtz builds: measured there; the packed-index build of p = 4 sits at its 168 registers and would spill two)
+#define BP5_PRIO_ON (BP::LATT || (ABL & 8388608) != 0)
+#define BP5_PRIO_HI if constexpr (BP5_SETPRIO != 0 && BP5_PRIO_ON) __builtin_amdgcn_s_setprio(BP5_SETPRIO);
+#define BP5_PRIO_LO if constexpr (BP5_SETPRIO != 0 && BP5_PRIO_ON) __builtin_amdgcn_s_setprio(0);
+#define BP5_PRIO_WO_HI if constexpr (BP5_SETPRIO_WO != 0 && BP5_PRIO_ON) __builtin_amdgcn_s_setprio(BP5_SETPRIO_WO);
+#define BP5_PRIO_WO_LO if constexpr (BP5_SETPRIO_WO != 0 && BP5_PRIO_ON) __builtin_amdgcn_s_setprio(0);
 template <int P, bool COLL, int LPC, int SCATTER, int ABL = 0>
 __global__ void __launch_bounds__(256, (block_wg_per_cu<P, ABL>())) apply_block_kernel(ApplyArgs a, BlockPlan bp, ShapeArg<P + 1> sh)
 {
