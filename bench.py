@@ -643,10 +643,12 @@ def main():
             bq, xq = oq.assemble_rhs(), oq.initialize_dof_vector()
             timed_solve(3, oq, xq, bq)
             timed_solve(8, oq, xq, bq)   # (a second warm-up: the first entry of the sweep read 8 % low behind a single short one -- fresh allocations, clocks; profiles/r4 e_*, i_*)
-            cq, dq = timed_solve(max(10, min(args.steps, 30)), oq, xq, bq)
+            # best of two solves (the reference's own protocol takes the best repetition, bp5/step-64.cu:457-463): single solves of the sweep's first entry still
+            # read up to 13 % low on some boxes (p = 1 Gauss 9.8 with GLL at 11.2 on the same mesh a minute later; profiles/r4 y_bench_config4_final.json)
+            cq, dq = min((timed_solve(max(10, min(args.steps, 30)), oq, xq, bq) for _ in range(2)), key=lambda cd: cd[1])
             vq = int(mq.n_global_dofs) * cq.last_step() / dq
             e = {"value": vq, "ms_per_step": dq / max(cq.last_step(), 1) * 1e3, "kernel": cq.apply_kernel, "dot_products_fused": bool(cq.dot_products_fused),
-                 "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS}
+                 "frac_of_hbm_peak": vq * algorithmic_bytes_per_dof(q, mq.n_cells, mq.n_owned, G=G) / 1e9 / HBM_PEAK_GBS, "repetitions": 2}
             oq.mf_data.close()
             del oq, bq, xq
             torch.cuda.empty_cache()
