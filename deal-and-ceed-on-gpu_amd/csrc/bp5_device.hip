@@ -1362,10 +1362,7 @@ static int halo_streams(bp5_mf *mf)
   int prio_lo = 0, prio_hi = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   HIP_TRY(hipStreamCreateWithPriority(&mf->comm_stream, hipStreamNonBlocking, prio_hi));
-  // (probe, environment BP5_EVENT_RELEASE_TO_DEVICE=1, read once here: device-scope instead of system-scope release when the exchange's events are recorded --
-  // how much of the 21-28 us in front of a kernel that waits for another queue is the fence?  Off by default: data that travels to a peer GPU needs the system scope)
-  const unsigned ev_flags = hipEventDisableTiming | ((getenv("BP5_EVENT_RELEASE_TO_DEVICE") && atoi(getenv("BP5_EVENT_RELEASE_TO_DEVICE"))) ? hipEventReleaseToDevice : 0u);
-  for (hipEvent_t &e : mf->ev_halo) HIP_TRY(hipEventCreateWithFlags(&e, ev_flags));
+  for (hipEvent_t &e : mf->ev_halo) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); // (hipEventReleaseToDevice was tried: +20 us per iteration, profiles/r4 z_*)
   // boundary-first schedule inside ONE launch: the communication stream waits for a counter the block kernel's workgroups bump once
   // their ghost-touching bricks are written out (hipStreamWaitValue64).  The counter is plain device memory: there the runtime implements
   // the wait by POLLING (profiles/r3/a_wait_value_probe.txt: same timing as a spin kernel; on signal memory the wait released only after
